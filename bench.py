@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the QPSK receive hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+
+One "step" = one pass of the fused RRC-FIR + Costas + slicer kernel (qpsk_rx_batch, fixed timing
+offset: BASELINE.json configs[1], "Batch 4096 frames x 16384 complex samples, RRC FIR + Costas on 1
+MI355X") over one batch of synthetic frames that is already resident in HBM.  With N > 1 the driver
+starts one process per GPU (torch.distributed.run); every rank owns its own independent batch of the
+same size (frames are independent: no data-path collective); the only communication is
+the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (see the keys at the bottom).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FS, RS, L = 19200.0, 2400.0, 16384        # 2400 baud, 8x oversample, 16384 complex samples per frame
+CYCLES = 8
+FIXED_INDEX = 6                            # TX RRC (63) + RX RRC (63) group delay = 126 = 15*8 + 6
+HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+BYTES_PER_SAMPLE = 8                       # one complex float read per input sample
+
+
+def synth_frames_gpu(torch, dev, nframes, taps, seed, offset_hz=50.0):
+    """Synthetic QPSK frames built on the GPU (same recipe as tests/sigutil.make_frames: random dibits ->
+    Gray map -> zero-stuff x8 -> TX RRC with the RX taps -> +50 Hz rotation), float32 (F, L, 2)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    nsym = L // CYCLES
+    out = torch.empty((nframes, L, 2), dtype=torch.float32, device=dev)
+    const = torch.tensor([[1, 0], [0, 1], [0, -1], [-1, 0]], dtype=torch.float32, device=dev)  # qpsk.c:58-63
+    k = torch.from_numpy(np.asarray(taps, np.float32)[::-1].copy()).to(dev).view(1, 1, -1) * 1.85
+    n = torch.arange(L, device=dev, dtype=torch.float64)
+    ang = 2.0 * np.pi * offset_hz * n / FS
+    cr, ci = torch.cos(ang).float(), torch.sin(ang).float()
+    chunk = 512
+    for f0 in range(0, nframes, chunk):
+        f1 = min(nframes, f0 + chunk)
+        s = torch.randint(0, 4, (f1 - f0, nsym), generator=g, device=dev)
+        up = torch.zeros((f1 - f0, 2, L), dtype=torch.float32, device=dev)
+        up[:, :, ::CYCLES] = const[s].permute(0, 2, 1)
+        y = torch.nn.functional.conv1d(torch.nn.functional.pad(up.reshape(-1, 1, L), (126, 0)), k).reshape(f1 - f0, 2, L)
+        out[f0:f1, :, 0] = y[:, 0] * cr - y[:, 1] * ci
+        out[f0:f1, :, 1] = y[:, 0] * ci + y[:, 1] * cr
+    return out
+
+
+def cpu_baseline(x_host, taps):
+    """The reference's CPU path timed on this box's host cores, on a bounded sample of the same frames.
+    kind "reference": oracle/_ref (the untouched reference compiled with its own Makefile flags, one core,
+    consecutive rx_frame() calls as in its main loop, qpsk.c:344-354) when that library travelled here;
+    otherwise kind "port": the oracle restatement (-O2), one core."""
+    from oracle.pyoracle import Oracle, Reference, TIMING_HIST, ref_available
+    nsamp = x_host.shape[0] * x_host.shape[1]
+    out = {}
+    if ref_available("c1"):
+        ref = Reference("c1")
+        ref.reset()
+        t0 = time.perf_counter()
+        for f in range(x_host.shape[0]):
+            ref.rx_cplx(x_host[f])
+        dt = time.perf_counter() - t0
+        out = dict(value=nsamp / dt / 1e6, unit="Msamples/s", cores=1, kind="reference",
+                   sample="%d frames x %d samples, consecutive rx_frame() calls on oracle/_ref (gcc -std=c11, no -O, as the reference Makefile)" % x_host.shape[:2])
+    orc = Oracle()
+    t0 = time.perf_counter()
+    orc.rx_batch(x_host, FS, RS, timing_mode=TIMING_HIST, threads=1)
+    dt1 = time.perf_counter() - t0
+    ncores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    orc.rx_batch(x_host, FS, RS, timing_mode=TIMING_HIST, threads=ncores)
+    dtn = time.perf_counter() - t0
+    port = dict(port_1core_msps=nsamp / dt1 / 1e6, port_allcores_msps=nsamp / dtn / 1e6, port_cores=ncores,
+                port_flags="gcc -O2 -ffp-contract=off, full-rate FIR + histogram timing + Costas (the reference's work)")
+    if not out:
+        out = dict(value=port["port_1core_msps"], unit="Msamples/s", cores=1, kind="port",
+                   sample="%d frames x %d samples, oracle restatement" % x_host.shape[:2])
+    out.update(port)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step (config 2: 4096)")
+    ap.add_argument("--cpu-frames", type=int, default=512, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import qpsk_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libqpsk_hip has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if not os.path.exists(qpsk_amd.lib_path()):
+        if rank == 0:
+            qpsk_amd.build()
+        if dist:
+            dist.barrier()
+
+    F = args.frames
+    m = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX,
+                       device=local)
+    # rank r owns frames [r*F, (r+1)*F) of the global batch (seeded by rank): independent shards, no exchange
+    x = synth_frames_gpu(torch, dev, F, m.taps, seed=1000 + rank)
+    sym = torch.empty((F, m.nsym), dtype=torch.uint8, device=dev)
+    freq = torch.empty((F,), dtype=torch.float32, device=dev)
+    phase = torch.empty((F,), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if dist:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        m.rx_batch_raw(x, F, sym, freq, phase)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.rx_batch_raw(x, F, sym, freq, phase)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch duration of the dominant kernel, HIP events on the launch stream (= torch's current stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in evs:
+        a.record()
+        m.rx_batch_raw(x, F, sym, freq, phase)
+        b.record()
+    torch.cuda.synchronize()
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    if rank != 0:
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    samples_per_step = world * F * L
+    value = samples_per_step * args.steps / elapsed / 1e6
+    achieved = BYTES_PER_SAMPLE * F * L / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("frames") == F and tj.get("frame_size") == L:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "complex Msamples/s demodulated + % HBM roofline, 2400-baud RRC+Costas path",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "batch %d frames x %d complex samples per GPU, 2400 baud, 8x oversample, fused RRC FIR + Costas + slicer, fixed timing offset %d (BASELINE configs[1])" % (F, L, FIXED_INDEX),
+                   "frames_per_gpu": F, "frame_size": L, "fs": FS, "rs": RS, "loop_bw": "TAU/100", "sharding": "independent frames per GPU, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "rx_fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * F * L},
+    }
+    if world == 1:
+        ncpu = min(args.cpu_frames, F)
+        if ncpu > 0:
+            xh = x[:ncpu].cpu().numpy()
+            res["cpu_baseline"] = cpu_baseline(xh, m.taps)
+        if not args.no_parity:
+            from oracle.pyoracle import Oracle, TIMING_FIXED
+            npar = min(256, F)
+            xh = x[:npar].cpu().numpy()
+            want = Oracle().rx_batch(xh, FS, RS, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX)
+            gs, gf, gp = sym[:npar].cpu().numpy(), freq[:npar].cpu().numpy(), phase[:npar].cpu().numpy()
+            res["parity"] = {"frames_checked": npar, "symbol_mismatches": int(np.sum(gs != want["sym"])),
+                             "freq_bit_mismatches": int(np.sum(gf.view(np.uint32) != want["freq"].view(np.uint32))),
+                             "phase_bit_mismatches": int(np.sum(gp.view(np.uint32) != want["phase"].view(np.uint32))),
+                             "mean_freq_hz": float(np.mean(gf.astype(np.float64) * RS / (2 * np.pi)))}
+    print(json.dumps(res))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

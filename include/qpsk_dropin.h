@@ -1,0 +1,89 @@
+/*
+ * qpsk_dropin.h -- the reference's own C entry points, served by the GPU.
+ *
+ * A program written against the reference's headers keeps its calls; it
+ * includes this header instead of rrc_fir.h / costas_loop.h / algorithms/fft.h
+ * and links libqpsk_hip.so instead of rrc_fir.c / costas_loop.c / fft.c.
+ * Signatures, argument meaning, in-place behaviour and the process-wide
+ * singleton state (one modem per process, not re-entrant) are the
+ * reference's.  Each prototype cites the declaration it replaces
+ * (file:line in the reference tree).
+ *
+ * C only: the by-value "complex float" parameters are C99 types
+ * (the reference headers pull in <complex.h> the same way).
+ *
+ * What the reference fixed with #defines (FS, RS, CENTER, FRAME_SIZE,
+ * qpsk.h:16-23) is set once with qpsk_dropin_configure(); without that call
+ * the shipped values apply (9600, 2400, 1500, 512).
+ *
+ * Failure: the reference's functions return void and cannot fail.  Here a
+ * missing GPU or a HIP error is fatal: the message goes to stderr and the
+ * process aborts.  Nothing is ever computed on the CPU instead.
+ */
+#ifndef QPSK_DROPIN_H
+#define QPSK_DROPIN_H
+
+#ifdef __cplusplus
+#error "qpsk_dropin.h is a C header (C99 complex by-value parameters); C++ callers use qpsk_hip.h"
+#endif
+
+#include <complex.h>
+#include <stdint.h>
+#include "qpsk_hip.h"
+
+/* ---- configuration that the reference hard-codes ---------------------- */
+/* p->fs, rs, frame_size replace FS, RS, FRAME_SIZE (qpsk.h:16-23); center_hz replaces CENTER
+ * (qpsk.h:18) in fbb_rx_rect = cmplxconj(TAU * CENTER / FS) (qpsk.c:342).  Resets all modem state.
+ * Does NOT build taps or the loop: call rrc_make() and create_control_loop() as main() does
+ * (qpsk.c:302,308). */
+int qpsk_dropin_configure(const qpsk_params *p, double center_hz);
+/* device to use (default: current HIP device); call before anything else */
+int qpsk_dropin_set_device(int device);
+void qpsk_dropin_shutdown(void);
+
+/* ---- rrc_fir.h --------------------------------------------------------- */
+void rrc_fir(complex float memory[], complex float sample[], int length); /* rrc_fir.h:16 */
+void rrc_make(float fs, float rs, float alpha);                           /* rrc_fir.h:17 */
+
+/* ---- costas_loop.h ----------------------------------------------------- */
+void create_control_loop(float loop_bw, float min_freq, float max_freq);  /* costas_loop.h:16 */
+float phase_detector(complex float sample);                               /* costas_loop.h:17 */
+void update_gains(void);                                                  /* costas_loop.h:18 */
+void advance_loop(float error);                                           /* costas_loop.h:19 */
+void phase_wrap(void);                                                    /* costas_loop.h:20 */
+void frequency_limit(void);                                               /* costas_loop.h:21 */
+void set_loop_bandwidth(float);                                           /* costas_loop.h:25 */
+void set_damping_factor(float);                                           /* costas_loop.h:26 */
+void set_alpha(float);                                                    /* costas_loop.h:27 */
+void set_beta(float);                                                     /* costas_loop.h:28 */
+void set_frequency(float);                                                /* costas_loop.h:29 */
+void set_phase(float);                                                    /* costas_loop.h:30 */
+void set_max_freq(float);                                                 /* costas_loop.h:31 */
+void set_min_freq(float);                                                 /* costas_loop.h:32 */
+float get_loop_bandwidth(void);                                           /* costas_loop.h:36 */
+float get_damping_factor(void);                                           /* costas_loop.h:37 */
+float get_alpha(void);                                                    /* costas_loop.h:38 */
+float get_beta(void);                                                     /* costas_loop.h:39 */
+float get_frequency(void);                                                /* costas_loop.h:40 */
+float get_phase(void);                                                    /* costas_loop.h:41 */
+float get_max_freq(void);                                                 /* costas_loop.h:42 */
+float get_min_freq(void);                                                 /* costas_loop.h:43 */
+
+/* ---- algorithms/fft.h -------------------------------------------------- */
+#define QPSK_NFFT 512                                                     /* fft.h:44 */
+void fft(complex double *in, complex double *out);                        /* fft.h:46 */
+void fftn(complex double *in, complex double *out, int n);                /* fft.h:47 */
+void ifft(complex double *in, complex double *out);                       /* fft.h:48 */
+void ifftn(complex double *in, complex double *out, int n);               /* fft.h:49 */
+
+/* ---- qpsk.c (file-static there, exported equivalents here) ------------- */
+void qpsk_demod(complex float symbol, int bits[]);                        /* qpsk.c:24,74-79 */
+void rx_frame(int16_t in[]);                                              /* qpsk.c:25,88-218 */
+
+/* what rx_frame() leaves in the reference's globals (qpsk.c:41,51) */
+const complex float *qpsk_dropin_costas_frame(void);   /* costas_frame[FRAME_SIZE/CYCLES] */
+const uint8_t *qpsk_dropin_symbols(void);              /* (bits[1]<<1)|bits[0] per symbol, qpsk.c:209 */
+float qpsk_dropin_offset_freq(void);                   /* fbb_offset_freq, qpsk.c:217 */
+int qpsk_dropin_timing_index(void);                    /* index, qpsk.c:105,173-180 */
+
+#endif /* QPSK_DROPIN_H */

@@ -1,0 +1,184 @@
+/*
+ * qpsk_hip.h -- C ABI of libqpsk_hip.so, the MI355X (gfx950) implementation of
+ * the MonsieurETM/QPSK receive path:
+ *
+ *     rrc_fir()  ->  timing estimate  ->  Costas loop  ->  symbol slicer
+ *     (reference qpsk.c:88-218, rrc_fir.c:17-30, costas_loop.c:44-74)
+ *
+ * Two layers, both plain C (pointers and sizes only, no C++/torch types):
+ *
+ *  1. qpsk_dropin.h -- the reference's own function signatures (rrc_fir,
+ *     rrc_make, the costas_loop.h API, fft/fftn/ifft/ifftn, rx_frame,
+ *     qpsk_demod) as process-wide singletons, exactly as the reference has
+ *     them; they run on the GPU through layer 2.
+ *
+ *  2. this file -- context-carrying BATCHED entry points, the form in which
+ *     the path is fast: many independent frames (or streams) per call, data
+ *     already resident in HBM, one HIP stream per context.
+ *
+ * Conventions
+ *   - complex float  == float[2]  (re, im) == HIP float2   (rrc_fir.h:16)
+ *   - complex double == double[2]                          (fft.h:46-49)
+ *   - every "d_" pointer is DEVICE memory on the context's GPU; "h_" is host.
+ *   - every function returns QPSK_OK (0) or a negative qpsk_status; the text
+ *     of the last error of the calling thread is qpsk_last_error().
+ *     The reference itself has no error paths (all void); anything that could
+ *     only fail here (no GPU, bad shape, HIP error) is reported, never
+ *     silently computed on the CPU: there is NO host fallback in this library.
+ *   - calls on one context are ordered on its stream; outputs are valid after
+ *     qpsk_ctx_sync() (or after synchronising the stream the caller supplied).
+ */
+#ifndef QPSK_HIP_H
+#define QPSK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPSK_NTAPS 127 /* rrc_fir.h:13 */
+
+typedef enum {
+    QPSK_OK = 0,
+    QPSK_ERR_NO_DEVICE = -1, /* no HIP device / device index out of range */
+    QPSK_ERR_ARG = -2,       /* null pointer, non-positive size, frame_size % cycles != 0, ... */
+    QPSK_ERR_HIP = -3,       /* a HIP runtime call or a kernel launch failed */
+    QPSK_ERR_ALLOC = -4,
+    QPSK_ERR_STATE = -5      /* call sequence error (e.g. stream call on a context made for 0 streams) */
+} qpsk_status;
+
+/* How the decimation offset ("index", qpsk.c:105,173-180,190) is chosen. */
+typedef enum {
+    QPSK_TIMING_HIST = 0,  /* the reference's amplitude-histogram heuristic, qpsk.c:127-180 */
+    QPSK_TIMING_FIXED = 1, /* caller-supplied offset: the bandwidth-bound fused kernel */
+    QPSK_TIMING_FFT = 2    /* symbol-rate spectral line of |y|^2 via the radix-2 FFT (new design, no
+                              reference counterpart: SURVEY section 0, 8(a) A7) */
+} qpsk_timing_mode;
+
+/* The reference's compile-time #defines and main()'s literals as run-time
+ * parameters (qpsk.h:16-23, qpsk.c:302,308). */
+typedef struct {
+    double fs;          /* FS, sample rate in Hz                        qpsk.h:16 */
+    double rs;          /* RS, symbol rate in Hz; CYCLES = (int)(fs/rs) qpsk.h:17,21 */
+    int frame_size;     /* FRAME_SIZE, complex samples per frame/block  qpsk.h:23 */
+    float rrc_alpha;    /* third argument of rrc_make()                 qpsk.c:308 */
+    float loop_bw;      /* create_control_loop(loop_bw, min, max)       qpsk.c:302 */
+    float min_freq;
+    float max_freq;
+    int timing_mode;    /* qpsk_timing_mode */
+    int fixed_index;    /* used by QPSK_TIMING_FIXED, 0 <= fixed_index */
+} qpsk_params;
+
+typedef struct qpsk_ctx qpsk_ctx;
+
+const char *qpsk_last_error(void);
+const char *qpsk_version(void);
+int qpsk_device_count(void);
+
+/* main()'s defaults: FS 9600, RS 2400, FRAME_SIZE 512, alpha .35, loop TAU/100, clamp +-1 (qpsk.c:302,308) */
+void qpsk_params_default(qpsk_params *p);
+
+/* device < 0: current HIP device.  stream: a hipStream_t to run on, or NULL for a private one. */
+int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stream);
+void qpsk_ctx_destroy(qpsk_ctx *ctx);
+int qpsk_ctx_sync(qpsk_ctx *ctx);
+int qpsk_ctx_set_stream(qpsk_ctx *ctx, void *stream);
+int qpsk_ctx_cycles(const qpsk_ctx *ctx);   /* CYCLES */
+int qpsk_ctx_nsym(const qpsk_ctx *ctx);     /* FRAME_SIZE / CYCLES */
+
+/* Host-side copies of what rrc_make() / create_control_loop() produced for this context. */
+int qpsk_ctx_get_taps(const qpsk_ctx *ctx, float h_taps[QPSK_NTAPS]);
+int qpsk_ctx_get_gains(const qpsk_ctx *ctx, float *h_alpha, float *h_beta);
+/* Replace them (the reference lets the caller do both: rrc_make(), set_alpha()/set_beta()). */
+int qpsk_ctx_set_taps(qpsk_ctx *ctx, const float h_taps[QPSK_NTAPS]);
+int qpsk_ctx_set_loop(qpsk_ctx *ctx, float alpha, float beta, float min_freq, float max_freq);
+
+/* -------------------------------------------------------------------------
+ * Batch of INDEPENDENT frames -- the hot path.
+ *
+ * For each of nframes frames of frame_size complex samples this is, bit for
+ * bit, what the reference computes with a fresh process:
+ *       rx_frame(frame); rx_frame(zeros);      (qpsk.c:88-218; complex input
+ * enters at the rrc_fir() call, qpsk.c:125; the second call is the flush that
+ * the one-block pipeline delay of qpsk.c:186-197 needs)
+ * taking costas_frame[], the slicer bits and the loop state after the second
+ * call.
+ *
+ *   d_in      [nframes][frame_size] complex float
+ *   d_sym     [nframes][nsym] uint8   (bits[1]<<1)|bits[0] of qpsk_demod(), qpsk.c:74-79,270
+ *   d_freq    [nframes] float         get_frequency() after the frame  (rad/symbol)
+ *   d_phase   [nframes] float         get_phase()
+ *   d_costas  [nframes][nsym] complex float, costas_frame[] (qpsk.c:197)   -- may be NULL
+ *   d_index   [nframes] int32, the decimation offset used                  -- may be NULL
+ *   d_hz      [nframes] float, fbb_offset_freq = freq*RS/TAU (qpsk.c:217)  -- may be NULL
+ * ------------------------------------------------------------------------- */
+int qpsk_rx_batch(qpsk_ctx *ctx, const float *d_in, int nframes, uint8_t *d_sym, float *d_freq,
+                  float *d_phase, float *d_costas, int32_t *d_index, float *d_hz);
+
+/* The same with nbw Costas loops per frame sharing one FIR pass (loop
+ * bandwidth sweep, README.md:12).  Outputs are [nframes][nbw][...]. */
+int qpsk_rx_batch_bw(qpsk_ctx *ctx, const float *d_in, int nframes, const float *h_loop_bw, int nbw,
+                     uint8_t *d_sym, float *d_freq, float *d_phase, int32_t *d_index);
+
+/* -------------------------------------------------------------------------
+ * The stages on their own (each is what the corresponding reference function
+ * computes, batched).
+ * ------------------------------------------------------------------------- */
+
+/* rrc_fir() (rrc_fir.c:17-30) on nframes independent delay lines.
+ *   d_memory [nframes][127] complex float  in/out (may be NULL: zero history, not written back)
+ *   d_in, d_out [nframes][length] complex float; d_out may equal d_in only if nframes*length
+ *   fits the library's staging (it copies first); prefer separate buffers. */
+int qpsk_rrc_fir_batch(qpsk_ctx *ctx, float *d_memory, const float *d_in, float *d_out, int nframes, int length);
+
+/* timing histogram (qpsk.c:127-180) of nframes filtered blocks -> d_index[nframes] */
+int qpsk_timing_hist_batch(qpsk_ctx *ctx, const float *d_filtered, int nframes, int32_t *d_index);
+
+/* Costas loop + slicer (qpsk.c:196-212) over already decimated symbols.
+ *   d_symbols_in [nframes][nsym] complex float;  d_state [nframes][2] float (phase, freq) in/out,
+ *   NULL = start from (0,0) and do not write back. */
+int qpsk_costas_batch(qpsk_ctx *ctx, const float *d_symbols_in, int nframes, int nsym, float *d_state,
+                      uint8_t *d_sym, float *d_costas);
+
+/* fftn()/ifftn() (fft.c:110-136) on nbatch independent length-n transforms, n a power of two.
+ *   d_in, d_out [nbatch][n] complex double; forward is scaled by 1/n, inverse is not (fft.c:105-107). */
+int qpsk_fft_batch(qpsk_ctx *ctx, const double *d_in, double *d_out, int nbatch, int n, int inverse);
+
+/* -------------------------------------------------------------------------
+ * STREAMS: nstreams modems advancing one block per call with all state
+ * carried, i.e. consecutive rx_frame() calls (qpsk.c:344-354): FIR delay
+ * line, previous block's symbols, Costas phase/frequency, mixer phase.
+ * Results are those of the PREVIOUS block (qpsk.c:186-197), as in the
+ * reference.
+ * ------------------------------------------------------------------------- */
+int qpsk_streams_reset(qpsk_ctx *ctx, int nstreams, double mixer_hz);
+/* the carried Costas state, h_state[nstreams][2] = (phase, freq): set_phase()/set_frequency() and
+ * get_phase()/get_frequency() for every stream at once (costas_loop.c:117-132,148-150) */
+int qpsk_streams_set_loop_state(qpsk_ctx *ctx, const float *h_state);
+int qpsk_streams_get_loop_state(qpsk_ctx *ctx, float *h_state);
+/* complex input (enters at qpsk.c:125) */
+int qpsk_streams_rx_cplx(qpsk_ctx *ctx, const float *d_in, uint8_t *d_sym, float *d_freq, float *d_phase,
+                         float *d_costas, int32_t *d_index);
+/* int16 PCM input, mixed to complex on the GPU (qpsk.c:114-120) */
+int qpsk_streams_rx_pcm(qpsk_ctx *ctx, const int16_t *d_pcm, uint8_t *d_sym, float *d_freq, float *d_phase,
+                        float *d_costas, int32_t *d_index);
+
+/* -------------------------------------------------------------------------
+ * Small helpers so that a C host needs nothing but this library.
+ * ------------------------------------------------------------------------- */
+int qpsk_dev_alloc(qpsk_ctx *ctx, void **d_ptr, size_t bytes);
+int qpsk_dev_free(qpsk_ctx *ctx, void *d_ptr);
+int qpsk_dev_upload(qpsk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int qpsk_dev_download(qpsk_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* Self-test hook: order-independent 64-bit hash of the device sin/cos (the glibc-exact routine the
+ * Costas kernel uses) over the float bit patterns [first, first+count) in both signs; tests compare
+ * it with the same hash of the CPU oracle over the same range. */
+int qpsk_selftest_sincos_hash(qpsk_ctx *ctx, uint32_t first, uint32_t count, unsigned long long *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPSK_HIP_H */

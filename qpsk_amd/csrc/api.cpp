@@ -1,0 +1,612 @@
+/*
+ * api.cpp -- the C ABI of include/qpsk_hip.h: contexts, argument checking,
+ * scratch management and kernel sequencing.  No arithmetic of the receive
+ * path happens here: per-configuration numbers come from host_math.c (as in
+ * the reference, on the host), everything per sample runs in kernels.hip.
+ * There is deliberately no CPU fallback: without a usable GPU every entry
+ * point fails with QPSK_ERR_NO_DEVICE / QPSK_ERR_HIP.
+ */
+#include "../../include/qpsk_hip.h"
+#include "host_math.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <vector>
+
+using namespace qpsk;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(QPSK_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define KERNEL_TRY(expr)                                                                      \
+    do {                                                                                      \
+        int e_ = (expr);                                                                      \
+        if (e_ != 0)                                                                          \
+            return fail(QPSK_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString((hipError_t)e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct qpsk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    qpsk_params prm{};
+    int cycles = 0, nsym = 0;
+    float taps[QPSK_NTAPS];
+    float damping = 0.f, alpha = 0.f, beta = 0.f;
+    float min_freq = 0.f, max_freq = 0.f;
+    float *d_taps = nullptr;     /* 128 floats */
+    float *d_gains = nullptr;    /* MAX_BW x (alpha, beta) */
+    std::vector<float> h_gains;
+    DevBuf index, filtered, mixed;
+    std::map<int, double *> twiddles;
+    /* streams */
+    int nstreams = 0;
+    float *s_memory = nullptr, *s_dec = nullptr, *s_loop = nullptr, *s_mixer = nullptr;
+};
+
+static const int MAX_BW = 64;
+
+static int ensure(qpsk_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (b.cap >= bytes) return QPSK_OK;
+    if (b.p) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(QPSK_ERR_ALLOC, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    b.cap = bytes;
+    return QPSK_OK;
+}
+
+static int bind(const qpsk_ctx *c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    return QPSK_OK;
+}
+
+/* make d_gains[0] the context's own (alpha, beta) again after a bandwidth sweep replaced it */
+static int use_context_gains(qpsk_ctx *c)
+{
+    const float g[2] = {c->alpha, c->beta};
+    if (c->h_gains.size() != 2 || c->h_gains[0] != g[0] || c->h_gains[1] != g[1]) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->h_gains.assign(g, g + 2);
+        HIP_TRY(hipMemcpyAsync(c->d_gains, c->h_gains.data(), sizeof g, hipMemcpyHostToDevice, c->stream));
+    }
+    return QPSK_OK;
+}
+
+extern "C" {
+
+const char *qpsk_last_error(void) { return g_err; }
+const char *qpsk_version(void) { return "qpsk_hip 0.1 (gfx950)"; }
+
+int qpsk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void qpsk_params_default(qpsk_params *p)
+{
+    if (!p) return;
+    p->fs = 9600.0;
+    p->rs = 2400.0;
+    p->frame_size = 512;
+    p->rrc_alpha = .35f;
+    p->loop_bw = (float)(2.0 * 3.14159265358979323846 / 100.0f); /* (TAU / 100.0f), qpsk.c:302 */
+    p->min_freq = -1.0f;
+    p->max_freq = 1.0f;
+    p->timing_mode = QPSK_TIMING_HIST;
+    p->fixed_index = 0;
+}
+
+static int upload_config(qpsk_ctx *c)
+{
+    float t128[128];
+    memset(t128, 0, sizeof t128);
+    memcpy(t128, c->taps, sizeof c->taps);
+    HIP_TRY(hipMemcpyAsync(c->d_taps, t128, sizeof t128, hipMemcpyHostToDevice, c->stream));
+    const float g[2] = {c->alpha, c->beta};
+    c->h_gains.assign(g, g + 2);
+    HIP_TRY(hipMemcpyAsync(c->d_gains, c->h_gains.data(), sizeof g, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stream)
+{
+    if (!out || !p) return fail(QPSK_ERR_ARG, "qpsk_ctx_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(QPSK_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(QPSK_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, ndev);
+    if (!(p->fs > 0.0) || !(p->rs > 0.0) || p->frame_size <= 0)
+        return fail(QPSK_ERR_ARG, "fs, rs and frame_size must be positive");
+    const int cycles = (int)(p->fs / p->rs); /* qpsk.h:21 */
+    if (cycles < 1 || cycles > 64) return fail(QPSK_ERR_ARG, "CYCLES = (int)(fs/rs) = %d out of range 1..64", cycles);
+    if (p->frame_size % cycles != 0)
+        return fail(QPSK_ERR_ARG, "frame_size %d is not a multiple of CYCLES %d", p->frame_size, cycles);
+    if (p->timing_mode < QPSK_TIMING_HIST || p->timing_mode > QPSK_TIMING_FFT)
+        return fail(QPSK_ERR_ARG, "unknown timing_mode %d", p->timing_mode);
+    if (p->fixed_index < 0 || p->fixed_index > MAX_INDEX)
+        return fail(QPSK_ERR_ARG, "fixed_index %d outside 0..%d", p->fixed_index, MAX_INDEX);
+
+    HIP_TRY(hipSetDevice(device));
+    KERNEL_TRY(prepare_kernels());
+    qpsk_ctx *c = new qpsk_ctx();
+    c->device = device;
+    c->prm = *p;
+    c->cycles = cycles;
+    c->nsym = p->frame_size / cycles;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { delete c; return fail(QPSK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
+        c->own_stream = true;
+    }
+    qpsk_host_rrc_taps((float)p->fs, (float)p->rs, p->rrc_alpha, c->taps); /* rrc_make(FS, RS, alpha), qpsk.c:308 */
+    c->damping = sqrtf(2.0f) / 2.0f;                                        /* costas_loop.c:38 */
+    qpsk_host_loop_gains(c->damping, p->loop_bw, &c->alpha, &c->beta);
+    c->min_freq = p->min_freq;
+    c->max_freq = p->max_freq;
+    if (hipMalloc((void **)&c->d_taps, 128 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&c->d_gains, MAX_BW * 2 * sizeof(float)) != hipSuccess) {
+        qpsk_ctx_destroy(c);
+        return fail(QPSK_ERR_ALLOC, "hipMalloc of configuration buffers failed");
+    }
+    int rc = upload_config(c);
+    if (rc != QPSK_OK) { qpsk_ctx_destroy(c); return rc; }
+    *out = c;
+    return QPSK_OK;
+}
+
+static void free_streams(qpsk_ctx *c)
+{
+    hipFree(c->s_memory); hipFree(c->s_dec); hipFree(c->s_loop); hipFree(c->s_mixer);
+    c->s_memory = c->s_dec = c->s_loop = c->s_mixer = nullptr;
+    c->nstreams = 0;
+}
+
+void qpsk_ctx_destroy(qpsk_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    hipFree(c->d_taps);
+    hipFree(c->d_gains);
+    hipFree(c->index.p);
+    hipFree(c->filtered.p);
+    hipFree(c->mixed.p);
+    for (auto &kv : c->twiddles) hipFree(kv.second);
+    free_streams(c);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int qpsk_ctx_sync(qpsk_ctx *c)
+{
+    if (!c) return fail(QPSK_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_ctx_set_stream(qpsk_ctx *c, void *stream)
+{
+    if (!c) return fail(QPSK_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream) { hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return QPSK_OK;
+}
+
+int qpsk_ctx_cycles(const qpsk_ctx *c) { return c ? c->cycles : 0; }
+int qpsk_ctx_nsym(const qpsk_ctx *c) { return c ? c->nsym : 0; }
+
+int qpsk_ctx_get_taps(const qpsk_ctx *c, float *h)
+{
+    if (!c || !h) return fail(QPSK_ERR_ARG, "null argument");
+    memcpy(h, c->taps, sizeof c->taps);
+    return QPSK_OK;
+}
+
+int qpsk_ctx_get_gains(const qpsk_ctx *c, float *a, float *b)
+{
+    if (!c || !a || !b) return fail(QPSK_ERR_ARG, "null argument");
+    *a = c->alpha;
+    *b = c->beta;
+    return QPSK_OK;
+}
+
+int qpsk_ctx_set_taps(qpsk_ctx *c, const float *h)
+{
+    if (!c || !h) return fail(QPSK_ERR_ARG, "null argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    memcpy(c->taps, h, sizeof c->taps);
+    return upload_config(c);
+}
+
+int qpsk_ctx_set_loop(qpsk_ctx *c, float alpha, float beta, float min_freq, float max_freq)
+{
+    if (!c) return fail(QPSK_ERR_ARG, "null argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    c->alpha = alpha; c->beta = beta; c->min_freq = min_freq; c->max_freq = max_freq;
+    return upload_config(c);
+}
+
+/* ---------------------------------------------------------------- tiling */
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+/* frames per workgroup G and symbols per chunk S of rx_fused_kernel */
+static void pick_tiling(const qpsk_ctx *c, int nframes, int nbw, int *G, int *S)
+{
+    int g = nframes / 256;                 /* one workgroup per CU when the batch allows it */
+    if (g < 1) g = 1;
+    if (g > 64 / nbw) g = 64 / nbw;
+    if (g < 1) g = 1;
+    g = env_int("QPSK_FUSED_G", g);
+    if (g * nbw > 64) g = 64 / nbw;
+    int s = env_int("QPSK_FUSED_S", 64);
+    s &= ~7;
+    if (s < 8) s = 8;
+    const size_t budget = (size_t)env_int("QPSK_FUSED_LDS", 64 * 1024);
+    while (s > 8 && fused_lds_bytes(g, s, c->cycles, nbw) > budget) s -= 8;
+    while (g > 1 && fused_lds_bytes(g, s, c->cycles, nbw) > (size_t)MAX_LDS_BYTES) g--;
+    *G = g;
+    *S = s;
+}
+
+static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int32_t **d_index_out)
+{
+    *d_index_out = nullptr;
+    if (c->prm.timing_mode == QPSK_TIMING_FIXED) return QPSK_OK;
+    int rc = ensure(c, c->index, sizeof(int32_t) * (size_t)nframes);
+    if (rc) return rc;
+    if (c->prm.timing_mode == QPSK_TIMING_HIST) {
+        const size_t bytes = sizeof(float) * 2 * (size_t)nframes * c->prm.frame_size;
+        rc = ensure(c, c->filtered, bytes);
+        if (rc) return rc;
+        KERNEL_TRY(launch_rrc_fir(d_in, nullptr, (float *)c->filtered.p, c->d_taps, nframes, c->prm.frame_size, c->stream));
+        KERNEL_TRY(launch_timing_hist((const float *)c->filtered.p, nframes, c->prm.frame_size, c->cycles,
+                                      (int32_t *)c->index.p, c->stream));
+        *d_index_out = (const int32_t *)c->index.p;
+        return QPSK_OK;
+    }
+    return fail(QPSK_ERR_ARG, "timing mode %d is not implemented in this build", c->prm.timing_mode);
+}
+
+static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw, uint8_t *d_sym, float *d_freq,
+                           float *d_phase, float *d_costas, int32_t *d_index, float *d_hz)
+{
+    if (!c || !d_in || !d_sym) return fail(QPSK_ERR_ARG, "qpsk_rx_batch: null context, input or symbol buffer");
+    if (nframes <= 0) return fail(QPSK_ERR_ARG, "qpsk_rx_batch: nframes = %d", nframes);
+    if (bind(c)) return QPSK_ERR_HIP;
+    const int32_t *idx = nullptr;
+    int rc = timing_indices(c, d_in, nframes, &idx);
+    if (rc) return rc;
+
+    FusedArgs a{};
+    a.x = reinterpret_cast<const float2 *>(d_in);
+    a.nframes = nframes;
+    a.frame_size = c->prm.frame_size;
+    a.cycles = c->cycles;
+    a.nsym = c->nsym;
+    pick_tiling(c, nframes, nbw, &a.G, &a.S);
+    a.index = idx;
+    a.fixed_index = c->prm.fixed_index;
+    a.taps = c->d_taps;
+    a.gains = c->d_gains;
+    a.nbw = nbw;
+    a.min_freq = c->min_freq;
+    a.max_freq = c->max_freq;
+    a.rs = c->prm.rs;
+    a.sym = d_sym;
+    a.freq = d_freq;
+    a.phase = d_phase;
+    a.costas = reinterpret_cast<float2 *>(d_costas);
+    a.hz = d_hz;
+    KERNEL_TRY(launch_rx_fused(a, c->stream));
+    if (d_index) {
+        if (idx)
+            HIP_TRY(hipMemcpyAsync(d_index, idx, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToDevice, c->stream));
+        else
+            KERNEL_TRY(launch_fill_i32(d_index, nframes, c->prm.fixed_index, c->stream));
+    }
+    return QPSK_OK;
+}
+
+int qpsk_rx_batch(qpsk_ctx *c, const float *d_in, int nframes, uint8_t *d_sym, float *d_freq, float *d_phase,
+                  float *d_costas, int32_t *d_index, float *d_hz)
+{
+    if (c) {
+        if (bind(c)) return QPSK_ERR_HIP;
+        if (int rg = use_context_gains(c)) return rg;
+    }
+    return rx_batch_common(c, d_in, nframes, 1, d_sym, d_freq, d_phase, d_costas, d_index, d_hz);
+}
+
+int qpsk_rx_batch_bw(qpsk_ctx *c, const float *d_in, int nframes, const float *h_loop_bw, int nbw, uint8_t *d_sym,
+                     float *d_freq, float *d_phase, int32_t *d_index)
+{
+    if (!c || !h_loop_bw) return fail(QPSK_ERR_ARG, "qpsk_rx_batch_bw: null argument");
+    if (nbw < 1 || nbw > MAX_BW) return fail(QPSK_ERR_ARG, "nbw = %d outside 1..%d", nbw, MAX_BW);
+    if (bind(c)) return QPSK_ERR_HIP;
+    std::vector<float> g(2 * (size_t)nbw);
+    for (int b = 0; b < nbw; b++)
+        qpsk_host_loop_gains(c->damping, h_loop_bw[b], &g[2 * b], &g[2 * b + 1]); /* set_loop_bandwidth(), costas_loop.c:79-87 */
+    if (g != c->h_gains) {
+        HIP_TRY(hipStreamSynchronize(c->stream)); /* the previous upload may still read h_gains */
+        c->h_gains = g;
+        HIP_TRY(hipMemcpyAsync(c->d_gains, c->h_gains.data(), sizeof(float) * g.size(), hipMemcpyHostToDevice, c->stream));
+    }
+    return rx_batch_common(c, d_in, nframes, nbw, d_sym, d_freq, d_phase, nullptr, d_index, nullptr);
+}
+
+/* ---------------------------------------------------------------- stages */
+int qpsk_rrc_fir_batch(qpsk_ctx *c, float *d_memory, const float *d_in, float *d_out, int nframes, int length)
+{
+    if (!c || !d_in || !d_out) return fail(QPSK_ERR_ARG, "qpsk_rrc_fir_batch: null argument");
+    if (nframes <= 0 || length <= 0) return fail(QPSK_ERR_ARG, "qpsk_rrc_fir_batch: nframes %d length %d", nframes, length);
+    if (bind(c)) return QPSK_ERR_HIP;
+    const float *src = d_in;
+    if (d_in == d_out) {
+        /* rrc_fir() works in place (rrc_fir.c:28); a tiled kernel cannot, so filter from a copy */
+        const size_t bytes = sizeof(float) * 2 * (size_t)nframes * length;
+        int rc = ensure(c, c->mixed, bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->mixed.p, d_in, bytes, hipMemcpyDeviceToDevice, c->stream));
+        src = (const float *)c->mixed.p;
+    }
+    KERNEL_TRY(launch_rrc_fir(src, d_memory, d_out, c->d_taps, nframes, length, c->stream));
+    if (d_memory) KERNEL_TRY(launch_delay_line(src, d_memory, nframes, length, c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_timing_hist_batch(qpsk_ctx *c, const float *d_filtered, int nframes, int32_t *d_index)
+{
+    if (!c || !d_filtered || !d_index) return fail(QPSK_ERR_ARG, "qpsk_timing_hist_batch: null argument");
+    if (nframes <= 0) return fail(QPSK_ERR_ARG, "nframes = %d", nframes);
+    if (bind(c)) return QPSK_ERR_HIP;
+    KERNEL_TRY(launch_timing_hist(d_filtered, nframes, c->prm.frame_size, c->cycles, d_index, c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_costas_batch(qpsk_ctx *c, const float *d_symbols_in, int nframes, int nsym, float *d_state, uint8_t *d_sym,
+                      float *d_costas)
+{
+    if (!c || !d_symbols_in) return fail(QPSK_ERR_ARG, "qpsk_costas_batch: null argument");
+    if (nframes <= 0 || nsym <= 0) return fail(QPSK_ERR_ARG, "nframes %d nsym %d", nframes, nsym);
+    if (bind(c)) return QPSK_ERR_HIP;
+    if (int rg = use_context_gains(c)) return rg;
+    KERNEL_TRY(launch_costas(d_symbols_in, nframes, nsym, nsym, 1, c->d_gains, c->min_freq, c->max_freq, d_state, d_state,
+                             d_sym, d_costas, c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, int n, int inverse)
+{
+    if (!c || !d_in || !d_out) return fail(QPSK_ERR_ARG, "qpsk_fft_batch: null argument");
+    if (nbatch <= 0 || n < 1 || (n & (n - 1))) return fail(QPSK_ERR_ARG, "n = %d must be a power of two, nbatch %d > 0", n, nbatch);
+    if ((size_t)n * 16 > (size_t)MAX_LDS_BYTES) return fail(QPSK_ERR_ARG, "n = %d does not fit one workgroup's LDS (max %d)", n, MAX_LDS_BYTES / 16);
+    if (bind(c)) return QPSK_ERR_HIP;
+    int log2n = 0;
+    while ((1 << log2n) < n) log2n++;
+    double *tw = nullptr;
+    auto it = c->twiddles.find(n);
+    if (it == c->twiddles.end()) {
+        const size_t cnt = n >= 2 ? (size_t)n / 2 : 1;
+        std::vector<double> h(2 * cnt, 0.0);
+        qpsk_host_twiddles(n, h.data());
+        HIP_TRY(hipMalloc((void **)&tw, sizeof(double) * 2 * cnt));
+        HIP_TRY(hipMemcpy(tw, h.data(), sizeof(double) * 2 * cnt, hipMemcpyHostToDevice));
+        c->twiddles[n] = tw;
+    } else {
+        tw = it->second;
+    }
+    KERNEL_TRY(launch_fft(d_in, d_out, tw, nbatch, n, log2n, inverse ? 1 : 0, c->stream));
+    return QPSK_OK;
+}
+
+/* --------------------------------------------------------------- streams */
+int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
+{
+    if (!c || nstreams <= 0) return fail(QPSK_ERR_ARG, "qpsk_streams_reset: bad argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (nstreams != c->nstreams) {
+        free_streams(c);
+        const size_t n = (size_t)nstreams;
+        if (hipMalloc((void **)&c->s_memory, sizeof(float) * 2 * QPSK_NTAPS * n) != hipSuccess ||
+            hipMalloc((void **)&c->s_dec, sizeof(float) * 4 * c->nsym * n) != hipSuccess ||
+            hipMalloc((void **)&c->s_loop, sizeof(float) * 2 * n) != hipSuccess ||
+            hipMalloc((void **)&c->s_mixer, sizeof(float) * 4 * n) != hipSuccess) {
+            free_streams(c);
+            return fail(QPSK_ERR_ALLOC, "hipMalloc of stream state failed");
+        }
+        c->nstreams = nstreams;
+    }
+    const size_t n = (size_t)nstreams;
+    HIP_TRY(hipMemsetAsync(c->s_memory, 0, sizeof(float) * 2 * QPSK_NTAPS * n, c->stream));
+    HIP_TRY(hipMemsetAsync(c->s_dec, 0, sizeof(float) * 4 * c->nsym * n, c->stream));
+    HIP_TRY(hipMemsetAsync(c->s_loop, 0, sizeof(float) * 2 * n, c->stream));
+    /* fbb_rx_phase = cmplx(0.0f); fbb_rx_rect = cmplxconj(TAU * hz / FS)  (qpsk.c:341-342) */
+    float rect[2];
+    qpsk_host_rect(mixer_hz, c->prm.fs, rect);
+    std::vector<float> m(4 * n);
+    for (size_t i = 0; i < n; i++) { m[4 * i] = 1.0f; m[4 * i + 1] = 0.0f; m[4 * i + 2] = rect[0]; m[4 * i + 3] = rect[1]; }
+    HIP_TRY(hipMemcpyAsync(c->s_mixer, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_streams_set_loop_state(qpsk_ctx *c, const float *h_state)
+{
+    if (!c || !h_state) return fail(QPSK_ERR_ARG, "null argument");
+    if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
+    if (bind(c)) return QPSK_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(c->s_loop, h_state, sizeof(float) * 2 * (size_t)c->nstreams, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_streams_get_loop_state(qpsk_ctx *c, float *h_state)
+{
+    if (!c || !h_state) return fail(QPSK_ERR_ARG, "null argument");
+    if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
+    if (bind(c)) return QPSK_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(h_state, c->s_loop, sizeof(float) * 2 * (size_t)c->nstreams, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *d_freq, float *d_phase,
+                         float *d_costas, int32_t *d_index)
+{
+    if (!c || !d_in) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_cplx: null argument");
+    if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
+    if (bind(c)) return QPSK_ERR_HIP;
+    const int n = c->nstreams, L = c->prm.frame_size, N = c->nsym;
+    int rc = ensure(c, c->filtered, sizeof(float) * 2 * (size_t)n * L);
+    if (rc) return rc;
+    rc = ensure(c, c->index, sizeof(int32_t) * (size_t)n);
+    if (rc) return rc;
+    float *filt = (float *)c->filtered.p;
+    int32_t *idx = (int32_t *)c->index.p;
+    /* qpsk.c:125 */
+    KERNEL_TRY(launch_rrc_fir(d_in, c->s_memory, filt, c->d_taps, n, L, c->stream));
+    KERNEL_TRY(launch_delay_line(d_in, c->s_memory, n, L, c->stream));
+    /* qpsk.c:127-180 */
+    if (c->prm.timing_mode == QPSK_TIMING_HIST)
+        KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, c->stream));
+    else if (c->prm.timing_mode == QPSK_TIMING_FIXED)
+        KERNEL_TRY(launch_fill_i32(idx, n, c->prm.fixed_index, c->stream));
+    else
+        return fail(QPSK_ERR_ARG, "timing mode %d is not implemented in this build", c->prm.timing_mode);
+    /* qpsk.c:186-191 */
+    KERNEL_TRY(launch_decimate(filt, idx, c->s_dec, n, L, c->cycles, N, c->stream));
+    /* qpsk.c:196-212 over the lower half (= the previous block) */
+    if (int rg = use_context_gains(c)) return rg;
+    KERNEL_TRY(launch_costas(c->s_dec, n, N, 2 * N, 1, c->d_gains, c->min_freq, c->max_freq, c->s_loop, c->s_loop, d_sym,
+                             d_costas, c->stream));
+    if (d_index) HIP_TRY(hipMemcpyAsync(d_index, idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    if (d_phase) HIP_TRY(hipMemcpy2DAsync(d_phase, sizeof(float), c->s_loop, 2 * sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, c->stream));
+    if (d_freq) HIP_TRY(hipMemcpy2DAsync(d_freq, sizeof(float), c->s_loop + 1, 2 * sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float *d_freq, float *d_phase,
+                        float *d_costas, int32_t *d_index)
+{
+    if (!c || !d_pcm) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_pcm: null argument");
+    if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
+    if (bind(c)) return QPSK_ERR_HIP;
+    const int n = c->nstreams, L = c->prm.frame_size;
+    int rc = ensure(c, c->mixed, sizeof(float) * 2 * (size_t)n * L);
+    if (rc) return rc;
+    /* qpsk.c:114-120 */
+    KERNEL_TRY(launch_mixer(d_pcm, (float *)c->mixed.p, c->s_mixer, n, L, c->stream));
+    return qpsk_streams_rx_cplx(c, (const float *)c->mixed.p, d_sym, d_freq, d_phase, d_costas, d_index);
+}
+
+/* ---------------------------------------------------------------- memory */
+int qpsk_dev_alloc(qpsk_ctx *c, void **d_ptr, size_t bytes)
+{
+    if (!c || !d_ptr) return fail(QPSK_ERR_ARG, "null argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    hipError_t e = hipMalloc(d_ptr, bytes);
+    if (e != hipSuccess) return fail(QPSK_ERR_ALLOC, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return QPSK_OK;
+}
+
+int qpsk_dev_free(qpsk_ctx *c, void *d_ptr)
+{
+    if (!c) return fail(QPSK_ERR_ARG, "null argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return QPSK_OK;
+}
+
+int qpsk_dev_upload(qpsk_ctx *c, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (!c || !d_dst || !h_src) return fail(QPSK_ERR_ARG, "null argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_dev_download(qpsk_ctx *c, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (!c || !h_dst || !d_src) return fail(QPSK_ERR_ARG, "null argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QPSK_OK;
+}
+
+/* test hook: order-independent hash of the device sin/cos over float bit patterns [first, first+count) in both signs */
+int qpsk_selftest_sincos_hash(qpsk_ctx *c, uint32_t first, uint32_t count, unsigned long long *h_out)
+{
+    if (!c || !h_out) return fail(QPSK_ERR_ARG, "null argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof *d));
+    HIP_TRY(hipMemsetAsync(d, 0, sizeof *d, c->stream));
+    KERNEL_TRY(launch_sincos_hash(first, count, d, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_out, d, sizeof *d, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(d));
+    return QPSK_OK;
+}
+
+} /* extern "C" */

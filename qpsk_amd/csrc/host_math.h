@@ -1,0 +1,19 @@
+/* host_math.h -- host-side configuration arithmetic (see host_math.c) */
+#ifndef QPSK_HOST_MATH_H
+#define QPSK_HOST_MATH_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPSK_HOST_NTAPS 127
+
+void qpsk_host_rrc_taps(float fs, float rs, float alpha, float taps[QPSK_HOST_NTAPS]);
+void qpsk_host_loop_gains(float damping, float loop_bw, float *alpha, float *beta);
+void qpsk_host_rect(double hz, double fs, float rect[2]);
+void qpsk_host_twiddles(int n, double *tw); /* tw[n/2][2] = cos, sin of 2 pi m / n */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,54 @@
+/* kernels.h -- launch interface between the C-ABI layer (api.cpp) and kernels.hip */
+#ifndef QPSK_KERNELS_H
+#define QPSK_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace qpsk {
+
+constexpr int LOOKBACK = 128;  /* >= 126 samples of FIR history, kept 16-byte friendly */
+constexpr int LOOKAHEAD = 8;   /* the decimation offset can reach 7 (qpsk.c:173-180) */
+constexpr int MAX_LDS_BYTES = 160 * 1024;
+constexpr int MAX_INDEX = 7;
+
+struct FusedArgs {
+    const float2 *x;        /* [nframes][frame_size] */
+    int nframes, frame_size, cycles, nsym;
+    int G, S;               /* frames per workgroup, symbols per chunk */
+    const int32_t *index;   /* [nframes] or NULL -> fixed_index */
+    int fixed_index;
+    const float *taps;      /* [127] */
+    const float *gains;     /* [nbw][2] alpha, beta */
+    int nbw;
+    float min_freq, max_freq;
+    double rs;
+    const float *state_in;  /* [nframes][nbw][2] phase, freq or NULL */
+    float *state_out;       /* same or NULL */
+    uint8_t *sym;           /* [nframes][nbw][nsym] */
+    float *freq, *phase;    /* [nframes][nbw] or NULL */
+    float2 *costas;         /* [nframes][nbw][nsym] or NULL */
+    float *hz;              /* [nframes][nbw] or NULL */
+};
+
+size_t fused_lds_bytes(int G, int S, int cycles, int nbw);
+int prepare_kernels(void);
+int launch_rx_fused(const FusedArgs &a, hipStream_t s);
+int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
+                   hipStream_t s);
+int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s);
+int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, hipStream_t s);
+int launch_costas(const float *d, int nframes, int nsym, int dstride, int nbw, const float *gains, float min_freq,
+                  float max_freq, const float *state_in, float *state_out, uint8_t *sym, float *costas,
+                  hipStream_t s);
+int launch_decimate(const float *filtered, const int32_t *index, float *dec, int nstreams, int frame_size,
+                    int cycles, int nsym, hipStream_t s);
+int launch_mixer(const int16_t *pcm, float *out, float *state, int nstreams, int frame_size, hipStream_t s);
+int launch_fft(const double *in, double *out, const double *tw, int nbatch, int n, int log2n, int inverse,
+               hipStream_t s);
+int launch_fill_i32(int32_t *p, int n, int32_t v, hipStream_t s);
+int launch_sincos_hash(uint32_t first, uint32_t count, unsigned long long *acc, hipStream_t s);
+
+} // namespace qpsk
+#endif

@@ -1,0 +1,521 @@
+/*
+ * kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the QPSK receive path.
+ * Compile with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+ *
+ *   rx_fused_kernel       decimating RRC FIR + Costas loop + slicer, one pass over the input
+ *                         (reference rrc_fir.c:17-30 at the samples qpsk.c:190 keeps,
+ *                          qpsk.c:196-212, costas_loop.c:44-74)            -- the hot kernel
+ *   rrc_fir_kernel        full-rate rrc_fir() on a batch of delay lines (rrc_fir.c:17-30)
+ *   delay_line_kernel     the delay line rrc_fir() leaves behind (rrc_fir.c:19-20)
+ *   timing_hist_kernel    the amplitude-histogram timing estimate (qpsk.c:127-180)
+ *   costas_kernel         Costas + slicer over decimated symbols (qpsk.c:196-212)
+ *   decimate_kernel       qpsk.c:186-191 for the streaming mode
+ *   mixer_kernel          PCM -> complex mix (qpsk.c:114-120)
+ *   fft_kernel            radix-2 complex-double FFT (algorithms/fft.c:38-136)
+ *
+ * Bit-exactness rules: no FMA contraction, FIR taps summed
+ * 0..126 in one fp32 accumulator, sin/cos from sincos_f32.h, no shuffle-tree
+ * reductions over floating-point sums.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "qpsk_device.h"
+#include "kernels.h"
+
+namespace qpsk {
+
+/* ========================================================================
+ * rx_fused_kernel (V0: chunked, barrier-synchronised)
+ *
+ * One workgroup owns G consecutive frames and walks them in chunks of S
+ * symbols.  Per chunk: (1) all threads stage the S*C new samples of each
+ * frame plus the 126-sample history into LDS with coalesced 8-byte loads,
+ * (2) all threads compute the G*S decimated FIR outputs (taps in LDS,
+ * broadcast reads), (3) wave 0 runs the G*nbw Costas recurrences over the S
+ * symbols, one lane per (frame, loop), and stages symbols / costas_frame in
+ * LDS, (4) all threads write the staged outputs coalesced.
+ *
+ * HBM traffic: 8 B read per input sample (+ history re-reads that hit L2),
+ * 1 B written per symbol per loop.
+ * ======================================================================== */
+constexpr int FUSED_THREADS = 256;
+
+__global__ void __launch_bounds__(FUSED_THREADS)
+rx_fused_kernel(FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int G = a.G, S = a.S, C = a.cycles, L = a.frame_size, N = a.nsym, nbw = a.nbw;
+    const int W = S * C + LOOKBACK + LOOKAHEAD; /* samples staged per frame per chunk */
+    float *taps = reinterpret_cast<float *>(smem);                          /* 128 floats */
+    float2 *xs = reinterpret_cast<float2 *>(smem + 512);                    /* [G][W] */
+    float2 *ds = xs + (size_t)G * W;                                        /* [G][S] decimated symbols */
+    float2 *zs = ds + (size_t)G * S;                                        /* [G*nbw][S] costas_frame staging */
+    uint8_t *ss = reinterpret_cast<uint8_t *>(zs + (size_t)G * nbw * S);    /* [G*nbw][S] symbol staging */
+    int *idx = reinterpret_cast<int *>(ss + (size_t)G * nbw * S);           /* [G] */
+
+    const int tid = threadIdx.x;
+    const int f0 = blockIdx.x * G;
+    const int gcount = min(G, a.nframes - f0);
+
+    if (tid < 128)
+        taps[tid] = tid < NTAPS ? a.taps[tid] : 0.0f;
+    if (tid < G)
+        idx[tid] = (tid < gcount) ? (a.index ? a.index[f0 + tid] : a.fixed_index) : 0;
+
+    /* Costas lane state (wave 0 only) */
+    const int lane_g = tid / nbw, lane_b = tid % nbw;
+    const bool costas_lane = tid < gcount * nbw && tid < 64;
+    Loop st = {0.0f, 0.0f};
+    LoopGains lg = {0.0f, 0.0f, a.min_freq, a.max_freq};
+    if (costas_lane) {
+        lg.alpha = a.gains[2 * lane_b];
+        lg.beta = a.gains[2 * lane_b + 1];
+        if (a.state_in) {
+            st.phase = a.state_in[2 * ((size_t)(f0 + lane_g) * nbw + lane_b)];
+            st.freq = a.state_in[2 * ((size_t)(f0 + lane_g) * nbw + lane_b) + 1];
+        }
+    }
+    __syncthreads();
+
+    const int nchunks = (N + S - 1) / S;
+    for (int c = 0; c < nchunks; c++) {
+        const int sym0 = c * S;
+        const int base = sym0 * C - LOOKBACK; /* sample index of xs[g][0] */
+
+        /* (1) stage samples: zeros before the frame (fresh delay line) and past its end */
+        for (int i = tid; i < gcount * W; i += FUSED_THREADS) {
+            const int g = i / W, w = i - g * W;
+            const int n = base + w;
+            float2 v = make_float2(0.0f, 0.0f);
+            if (n >= 0 && n < L)
+                v = a.x[(size_t)(f0 + g) * L + n];
+            xs[(size_t)g * W + w] = v;
+        }
+        __syncthreads();
+
+        /* (2) decimated FIR: output (g, j) is the full-rate output at sample (sym0+j)*C + idx[g] */
+        for (int o = tid; o < gcount * S; o += FUSED_THREADS) {
+            const int g = o / S, j = o - g * S;
+            const int n = (sym0 + j) * C + idx[g];
+            float2 d = make_float2(0.0f, 0.0f);
+            if (n < L && sym0 + j < N) {
+                const float2 *w = xs + (size_t)g * W + (n - HIST - base);
+                float2 y = make_float2(0.0f, 0.0f);
+#pragma unroll 8
+                for (int k = 0; k < NTAPS; k++)
+                    fir_mac(y, w[k], taps[k]);
+                d = fir_gain(y);
+            }
+            ds[o] = d;
+        }
+        __syncthreads();
+
+        /* (3) the serial part: one lane per (frame, loop) */
+        if (costas_lane) {
+            const int cnt = min(S, N - sym0);
+            const float2 *dl = ds + (size_t)lane_g * S;
+            for (int j = 0; j < cnt; j++) {
+                const float2 z = costas_step(st, lg, dl[j]);
+                ss[(size_t)tid * S + j] = (uint8_t)slicer(z);
+                if (a.costas)
+                    zs[(size_t)tid * S + j] = z;
+            }
+        }
+        __syncthreads();
+
+        /* (4) coalesced write-out of the chunk */
+        {
+            const int cnt = min(S, N - sym0);
+            const int rows = gcount * nbw;
+            for (int i = tid; i < rows * cnt; i += FUSED_THREADS) {
+                const int r = i / cnt, j = i - r * cnt;
+                const size_t o = ((size_t)f0 * nbw + r) * N + sym0 + j;
+                a.sym[o] = ss[(size_t)r * S + j];
+                if (a.costas)
+                    a.costas[o] = zs[(size_t)r * S + j];
+            }
+        }
+        /* next chunk's staging overwrites xs/ds only after everyone passed the barrier above;
+         * ss/zs are rewritten in step (3) of the next chunk, after two more barriers */
+    }
+
+    if (costas_lane) {
+        const size_t o = (size_t)(f0 + lane_g) * nbw + lane_b;
+        if (a.freq) a.freq[o] = st.freq;
+        if (a.phase) a.phase[o] = st.phase;
+        if (a.hz) a.hz[o] = (float)((double)st.freq * a.rs / TAU); /* qpsk.c:217 */
+        if (a.state_out) {
+            a.state_out[2 * o] = st.phase;
+            a.state_out[2 * o + 1] = st.freq;
+        }
+    }
+}
+
+size_t fused_lds_bytes(int G, int S, int cycles, int nbw)
+{
+    const size_t W = (size_t)S * cycles + LOOKBACK + LOOKAHEAD;
+    size_t b = 512 + sizeof(float2) * ((size_t)G * W + (size_t)G * S + (size_t)G * nbw * S);
+    b += (size_t)G * nbw * S;      /* ss */
+    b = (b + 15) & ~(size_t)15;
+    b += sizeof(int) * (size_t)G;  /* idx */
+    return b;
+}
+
+/* ========================================================================
+ * rrc_fir_kernel: full-rate FIR.  grid = (chunks, frames); each workgroup
+ * produces FIR_TILE outputs of one delay line from FIR_TILE+126 staged
+ * inputs; history before the block comes from the caller's delay line
+ * (memory[1..126], memory[0] is shifted out by the first step, rrc_fir.c:19)
+ * or is zero.
+ * ======================================================================== */
+constexpr int FIR_THREADS = 256;
+constexpr int FIR_PER_THREAD = 4;
+constexpr int FIR_TILE = FIR_THREADS * FIR_PER_THREAD;
+
+__global__ void __launch_bounds__(FIR_THREADS)
+rrc_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ memory, float2 *__restrict__ y,
+               const float *__restrict__ taps_g, int length)
+{
+    __shared__ float taps[128];
+    __shared__ float2 xs[FIR_TILE + HIST];
+    const int tid = threadIdx.x, f = blockIdx.y;
+    const int n0 = blockIdx.x * FIR_TILE;
+    if (tid < 128)
+        taps[tid] = tid < NTAPS ? taps_g[tid] : 0.0f;
+    for (int i = tid; i < FIR_TILE + HIST; i += FIR_THREADS) {
+        const int n = n0 - HIST + i;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (n >= 0) {
+            if (n < length) v = x[(size_t)f * length + n];
+        } else if (memory) {
+            v = memory[(size_t)f * NTAPS + (NTAPS + n)]; /* n = -1 -> memory[126] */
+        }
+        xs[i] = v;
+    }
+    __syncthreads();
+    float2 acc[FIR_PER_THREAD];
+#pragma unroll
+    for (int r = 0; r < FIR_PER_THREAD; r++)
+        acc[r] = make_float2(0.0f, 0.0f);
+    for (int k = 0; k < NTAPS; k++) {
+        const float c = taps[k];
+#pragma unroll
+        for (int r = 0; r < FIR_PER_THREAD; r++)
+            fir_mac(acc[r], xs[r * FIR_THREADS + tid + k], c);
+    }
+#pragma unroll
+    for (int r = 0; r < FIR_PER_THREAD; r++) {
+        const int n = n0 + r * FIR_THREADS + tid;
+        if (n < length)
+            y[(size_t)f * length + n] = fir_gain(acc[r]);
+    }
+}
+
+/* memory <- last 127 samples of (memory ++ x)  (rrc_fir.c:19-20 applied length times) */
+__global__ void __launch_bounds__(128)
+delay_line_kernel(const float2 *__restrict__ x, float2 *memory, int length)
+{
+    const int f = blockIdx.x, i = threadIdx.x;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (i < NTAPS) {
+        const int src = i + length - NTAPS; /* index into x; negative -> old memory */
+        v = src >= 0 ? x[(size_t)f * length + src] : memory[(size_t)f * NTAPS + (i + length)];
+    }
+    __syncthreads();
+    if (i < NTAPS)
+        memory[(size_t)f * NTAPS + i] = v;
+}
+
+/* ========================================================================
+ * timing_hist_kernel: qpsk.c:127-180.  The running average is never reset
+ * (Q2) and the thresholds use the running maximum (Q3), so each component of
+ * each frame is one serial scan: one lane per (frame, I|Q).
+ * ======================================================================== */
+__global__ void __launch_bounds__(64)
+timing_hist_kernel(const float *__restrict__ y, int nframes, int frame_size, int cycles, int32_t *index)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int f = t >> 1, comp = t & 1;
+    int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (f < nframes) {
+        const float *p = y + (size_t)f * frame_size * 2 + comp;
+        float av = 0.0f, mx = 0.0f;
+        const float fc = (float)cycles;
+        for (int i = 0; i + cycles <= frame_size; i += cycles) {
+            for (int j = 0; j < cycles; j++)
+                av += fabsf(p[2 * (size_t)(i + j)]);
+            av = av / fc;
+            if (av > mx) mx = av;
+            const float hv = mx / 8.0f;
+            int k = 1;
+            for (; k < 8; k++)
+                if (av <= hv * (float)k) break;
+            /* no dynamic indexing of a private array: keep hist[] in registers */
+#pragma unroll
+            for (int q = 1; q < 8; q++)
+                hist[q] += (q == k) ? 1 : 0;
+        }
+    }
+    /* lanes 2f and 2f+1 hold hist_i and hist_q of frame f: integer add across the pair */
+    int hmax = 0, best = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int h = hist[q] + __shfl_xor(hist[q], 1);
+        if (h > hmax) { hmax = h; best = q; }
+    }
+    if (f < nframes && comp == 0)
+        index[f] = best;
+}
+
+/* ========================================================================
+ * costas_kernel: Costas + slicer over decimated symbols; one lane per
+ * (frame, loop).  d: nframes rows of nsym symbols, dstride symbols apart;
+ * outputs [nframes][nbw][nsym].
+ * ======================================================================== */
+__global__ void __launch_bounds__(64)
+costas_kernel(const float2 *__restrict__ d, int nframes, int nsym, int dstride, int nbw, const float *__restrict__ gains,
+              float min_freq, float max_freq, const float *state_in, float *state_out, uint8_t *sym,
+              float2 *costas)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= nframes * nbw) return;
+    const int f = t / nbw, b = t - f * nbw;
+    Loop st = {0.0f, 0.0f};
+    if (state_in) { st.phase = state_in[2 * t]; st.freq = state_in[2 * t + 1]; }
+    const LoopGains lg = {gains[2 * b], gains[2 * b + 1], min_freq, max_freq};
+    const float2 *p = d + (size_t)f * dstride;
+    for (int i = 0; i < nsym; i++) {
+        const float2 z = costas_step(st, lg, p[i]);
+        if (sym) sym[(size_t)t * nsym + i] = (uint8_t)slicer(z);
+        if (costas) costas[(size_t)t * nsym + i] = z;
+    }
+    if (state_out) { state_out[2 * t] = st.phase; state_out[2 * t + 1] = st.freq; }
+}
+
+/* ========================================================================
+ * decimate_kernel: qpsk.c:186-191.  dec: [nstreams][2*nsym]; the upper half
+ * moves down, the new block's picks go to the upper half.  A pick past the
+ * block (index >= cycles, Q5) is defined as 0.
+ * ======================================================================== */
+__global__ void __launch_bounds__(256)
+decimate_kernel(const float2 *__restrict__ filtered, const int32_t *__restrict__ index, float2 *dec,
+                int nstreams, int frame_size, int cycles, int nsym)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (i >= nsym) return;
+    float2 *row = dec + (size_t)f * 2 * nsym;
+    const int src = i * cycles + index[f];
+    const float2 v = src < frame_size ? filtered[(size_t)f * frame_size + src] : make_float2(0.0f, 0.0f);
+    row[i] = row[nsym + i];
+    row[nsym + i] = v;
+}
+
+/* ========================================================================
+ * mixer_kernel: qpsk.c:114-120.  phase *= rect per sample is a serial complex
+ * recurrence per stream: one lane per stream; the block is renormalised with
+ * cabsf (glibc hypotf: exact squares in fp64, one rounded add, sqrt, narrow).
+ * state: [nstreams][4] = phase.re, phase.im, rect.re, rect.im
+ * ======================================================================== */
+__global__ void __launch_bounds__(64)
+mixer_kernel(const int16_t *__restrict__ pcm, float2 *__restrict__ out, float *state, int nstreams, int frame_size)
+{
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= nstreams) return;
+    float pr = state[4 * f], pi = state[4 * f + 1];
+    const float rr = state[4 * f + 2], ri = state[4 * f + 3];
+    const int16_t *in = pcm + (size_t)f * frame_size;
+    float2 *o = out + (size_t)f * frame_size;
+    for (int i = 0; i < frame_size; i++) {
+        const float nr = pr * rr - pi * ri;
+        const float ni = pr * ri + pi * rr;
+        pr = nr;
+        pi = ni;
+        const float v = (float)in[i] / 16384.0f;
+        o[i] = make_float2(pr * v, pi * v);
+    }
+    const float mag = (float)sqrt((double)pr * (double)pr + (double)pi * (double)pi);
+    state[4 * f] = pr / mag;
+    state[4 * f + 1] = pi / mag;
+}
+
+/* ========================================================================
+ * fft_kernel: algorithms/fft.c as an in-LDS iterative radix-2 DIT.  The
+ * reference recursion (even/odd split, fft.c:40-52) is the bit-reversal
+ * permutation followed by log2(n) butterfly stages; the stage of size m uses
+ * w_k = cos(TAU k/m) -/+ j sin(TAU k/m) (fft.c:55-56, 85-86), which equals
+ * table entry k*(n/m) of the size-n table bit for bit (scaling the argument
+ * by a power of two is exact), so one host-built libm table serves every
+ * stage.  One workgroup per transform.
+ * ======================================================================== */
+__global__ void __launch_bounds__(256)
+fft_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, const double2 *__restrict__ tw, int n,
+           int log2n, int inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *v = reinterpret_cast<double2 *>(smem);
+    const int tid = threadIdx.x;
+    const double2 *src = in + (size_t)blockIdx.x * n;
+    double2 *dst = out + (size_t)blockIdx.x * n;
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int r = (int)(__brev((unsigned)i) >> (32 - log2n));
+        v[r] = src[i];
+    }
+    __syncthreads();
+    const double sgn = inverse ? 1.0 : -1.0;
+    for (int s = 1; s <= log2n; s++) {
+        const int half = 1 << (s - 1), stride = n >> s;
+        for (int b = tid; b < n / 2; b += blockDim.x) {
+            const int k = b & (half - 1);
+            const int lo = ((b >> (s - 1)) << s) + k, hi = lo + half;
+            const double2 w = tw[k * stride];
+            const double wr = w.x, wi = sgn * w.y;
+            const double2 e = v[lo], o = v[hi];
+            const double zr = wr * o.x - wi * o.y;
+            const double zi = wr * o.y + wi * o.x;
+            v[lo] = make_double2(e.x + zr, e.y + zi);
+            v[hi] = make_double2(e.x - zr, e.y - zi);
+        }
+        __syncthreads();
+    }
+    const double dn = (double)n;
+    for (int i = tid; i < n; i += blockDim.x) {
+        double2 r = v[i];
+        if (!inverse) { r.x = r.x / dn; r.y = r.y / dn; } /* fft.c:105-107,117-119 */
+        dst[i] = r;
+    }
+}
+
+__global__ void fill_i32_kernel(int32_t *p, int n, int32_t v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+/* exhaustive self-test support: order-independent hash of sincos_f32 over a range of float bit patterns */
+__global__ void sincos_hash_kernel(uint32_t first, uint32_t count, unsigned long long *acc)
+{
+    unsigned long long h = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint32_t u = first + i;
+        for (int sg = 0; sg < 2; sg++) {
+            const float y = __uint_as_float(u | ((uint32_t)sg << 31));
+            const SinCos r = sincos_f32(y);
+            unsigned long long v = ((unsigned long long)__float_as_uint(r.s) << 32) | __float_as_uint(r.c);
+            v ^= (unsigned long long)(u | ((uint32_t)sg << 31)) * 0x9E3779B97F4A7C15ull;
+            v *= 0xD6E8FEB86659FD93ull;
+            v ^= v >> 32;
+            h += v;
+        }
+    }
+    atomicAdd(acc, h);
+}
+
+/* ------------------------------------------------------------------------ launchers */
+#define LAUNCH_CHECK()                          \
+    do {                                        \
+        hipError_t e_ = hipGetLastError();      \
+        if (e_ != hipSuccess) return (int)e_;   \
+    } while (0)
+
+int launch_rx_fused(const FusedArgs &a, hipStream_t s)
+{
+    const int blocks = (a.nframes + a.G - 1) / a.G;
+    const size_t lds = fused_lds_bytes(a.G, a.S, a.cycles, a.nbw);
+    hipLaunchKernelGGL(rx_fused_kernel, dim3(blocks), dim3(FUSED_THREADS), lds, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int prepare_kernels(void)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    return (int)e;
+}
+
+int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
+                   hipStream_t s)
+{
+    dim3 grid((length + FIR_TILE - 1) / FIR_TILE, nframes);
+    hipLaunchKernelGGL(rrc_fir_kernel, grid, dim3(FIR_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
+                       reinterpret_cast<const float2 *>(memory), reinterpret_cast<float2 *>(y), taps, length);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s)
+{
+    hipLaunchKernelGGL(delay_line_kernel, dim3(nframes), dim3(128), 0, s, reinterpret_cast<const float2 *>(x),
+                       reinterpret_cast<float2 *>(memory), length);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, hipStream_t s)
+{
+    const int threads = nframes * 2;
+    hipLaunchKernelGGL(timing_hist_kernel, dim3((threads + 63) / 64), dim3(64), 0, s, y, nframes, frame_size,
+                       cycles, index);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_costas(const float *d, int nframes, int nsym, int dstride, int nbw, const float *gains, float min_freq,
+                  float max_freq, const float *state_in, float *state_out, uint8_t *sym, float *costas,
+                  hipStream_t s)
+{
+    const int threads = nframes * nbw;
+    hipLaunchKernelGGL(costas_kernel, dim3((threads + 63) / 64), dim3(64), 0, s,
+                       reinterpret_cast<const float2 *>(d), nframes, nsym, dstride, nbw, gains, min_freq, max_freq,
+                       state_in, state_out, sym, reinterpret_cast<float2 *>(costas));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_decimate(const float *filtered, const int32_t *index, float *dec, int nstreams, int frame_size,
+                    int cycles, int nsym, hipStream_t s)
+{
+    dim3 grid((nsym + 255) / 256, nstreams);
+    hipLaunchKernelGGL(decimate_kernel, grid, dim3(256), 0, s, reinterpret_cast<const float2 *>(filtered), index,
+                       reinterpret_cast<float2 *>(dec), nstreams, frame_size, cycles, nsym);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mixer(const int16_t *pcm, float *out, float *state, int nstreams, int frame_size, hipStream_t s)
+{
+    hipLaunchKernelGGL(mixer_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, s, pcm,
+                       reinterpret_cast<float2 *>(out), state, nstreams, frame_size);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_fft(const double *in, double *out, const double *tw, int nbatch, int n, int log2n, int inverse,
+               hipStream_t s)
+{
+    const int threads = n / 2 < 256 ? (n / 2 < 64 ? 64 : n / 2) : 256;
+    hipLaunchKernelGGL(fft_kernel, dim3(nbatch), dim3(threads), sizeof(double2) * (size_t)n, s,
+                       reinterpret_cast<const double2 *>(in), reinterpret_cast<double2 *>(out),
+                       reinterpret_cast<const double2 *>(tw), n, log2n, inverse);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_fill_i32(int32_t *p, int n, int32_t v, hipStream_t s)
+{
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n, v);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_sincos_hash(uint32_t first, uint32_t count, unsigned long long *acc, hipStream_t s)
+{
+    hipLaunchKernelGGL(sincos_hash_kernel, dim3(2048), dim3(256), 0, s, first, count, acc);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+} // namespace qpsk

@@ -1,0 +1,75 @@
+/*
+ * sincos_f32.h -- single-precision sin/cos with the results of the C library
+ * the reference links (glibc 2.35 sinf/cosf, called through cmplx()/cmplxconj(),
+ * reference qpsk.h:35-36; Costas call site qpsk.c:197).
+ *
+ * ROCm's own sinf/cosf round differently, and the QPSK slicer decides symbols
+ * that sit on a decision boundary, so the device evaluates the
+ * library's published algorithm itself: argument in fp64, n = round(x * 2/pi)
+ * by a 2^24-prescaled multiply and an integer shift, r = x - n*pi/2, then a
+ * degree-7 odd / degree-8 even polynomial in r, narrowed to fp32.
+ *
+ * Form used here: ONE path for every |x| < 120 (the library's separate
+ * "|x| < pi/4" and "|x| < 2^-12" branches give the same floats as the general
+ * path: n = 0 and r = x there), multiply-adds fused (the library's x86-64 FMA
+ * build).  tools/check_device_sincos.c runs exactly this header on the host
+ * over every float in [-120, 120] against libm: 0 mismatches; on the Costas
+ * domain [-2pi, 2pi] the non-FMA library build gives the same floats too.
+ *
+ * Domain: |x| < 120.  The Costas phase is wrapped to [-2pi, 2pi]
+ * (costas_loop.c:61-67).
+ */
+#ifndef QPSK_SINCOS_F32_H
+#define QPSK_SINCOS_F32_H
+
+#if defined(__HIPCC__)
+#define QPSK_HD __host__ __device__ __forceinline__
+#else
+#define QPSK_HD static inline
+#endif
+
+namespace qpsk {
+
+struct SinCos {
+    float s, c;
+};
+
+QPSK_HD SinCos sincos_f32(float y)
+{
+    const double x = (double)y;
+    /* n = nearest integer to x*2/pi, via the 2^24-scaled product truncated to int32 */
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int)r + 0x800000) >> 24;
+    const double xr = __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
+    const double x2 = xr * xr;
+
+    /* sine polynomial (odd in xr) */
+    const double x3 = xr * x2;
+    const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+    const double x7 = x3 * x2;
+    const double sa = __builtin_fma(x3, -0x1.555545995a603p-3, xr);
+    const double S = __builtin_fma(x7, s1, sa);
+
+    /* cosine polynomial (even) */
+    const double x4 = x2 * x2;
+    const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+    const double c1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 1.0);
+    const double x6 = x4 * x2;
+    const double ca = __builtin_fma(x4, 0x1.55553e1068f19p-5, c1);
+    const double Cc = __builtin_fma(x6, c2, ca);
+
+    /* quadrant: n&3 = 0:(S,C) 1:(C,-S) 2:(-S,-C) 3:(-C,S); negation is exact */
+    const float fs = (float)S, fc = (float)Cc;
+    SinCos o;
+    const float a = (n & 1) ? fc : fs;
+    const float b = (n & 1) ? fs : fc;
+    o.s = (n & 2) ? -a : a;
+    o.c = ((n + 1) & 2) ? -b : b;
+    /* the library returns its argument for tiny |x|; the polynomial only loses the sign of -0 */
+    if (y == 0.0f)
+        o.s = y;
+    return o;
+}
+
+} // namespace qpsk
+#endif

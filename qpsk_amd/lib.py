@@ -1,0 +1,287 @@
+"""ctypes binding of libqpsk_hip.so (include/qpsk_hip.h) for tests and bench.py.
+
+Device buffers are torch tensors on the context's GPU; only their data_ptr() crosses the C ABI.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TAU = 2.0 * 3.14159265358979323846
+TIMING_HIST, TIMING_FIXED, TIMING_FFT = 0, 1, 2
+NTAPS = 127
+
+
+class QpskError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """qpsk_params of include/qpsk_hip.h (the reference's #defines and main() literals)."""
+    _fields_ = [("fs", C.c_double), ("rs", C.c_double), ("frame_size", C.c_int), ("rrc_alpha", C.c_float),
+                ("loop_bw", C.c_float), ("min_freq", C.c_float), ("max_freq", C.c_float),
+                ("timing_mode", C.c_int), ("fixed_index", C.c_int)]
+
+
+def lib_path():
+    return os.path.join(HERE, "libqpsk_hip.so")
+
+
+def build(verbose=False):
+    """Compile qpsk_amd/csrc for gfx950 into qpsk_amd/libqpsk_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(HERE, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return lib_path()
+
+
+_LIB = None
+
+# every symbol include/qpsk_hip.h declares (tests check that the library exports all of them)
+API_SYMBOLS = [
+    "qpsk_last_error", "qpsk_version", "qpsk_device_count", "qpsk_params_default", "qpsk_ctx_create",
+    "qpsk_ctx_destroy", "qpsk_ctx_sync", "qpsk_ctx_set_stream", "qpsk_ctx_cycles", "qpsk_ctx_nsym",
+    "qpsk_ctx_get_taps", "qpsk_ctx_get_gains", "qpsk_ctx_set_taps", "qpsk_ctx_set_loop", "qpsk_rx_batch",
+    "qpsk_rx_batch_bw", "qpsk_rrc_fir_batch", "qpsk_timing_hist_batch", "qpsk_costas_batch", "qpsk_fft_batch",
+    "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
+    "qpsk_streams_rx_pcm", "qpsk_dev_alloc", "qpsk_dev_free", "qpsk_dev_upload", "qpsk_dev_download",
+    "qpsk_selftest_sincos_hash",
+]
+# every symbol include/qpsk_dropin.h declares
+DROPIN_SYMBOLS = [
+    "qpsk_dropin_configure", "qpsk_dropin_set_device", "qpsk_dropin_shutdown", "rrc_fir", "rrc_make",
+    "create_control_loop", "phase_detector", "update_gains", "advance_loop", "phase_wrap", "frequency_limit",
+    "set_loop_bandwidth", "set_damping_factor", "set_alpha", "set_beta", "set_frequency", "set_phase",
+    "set_max_freq", "set_min_freq", "get_loop_bandwidth", "get_damping_factor", "get_alpha", "get_beta",
+    "get_frequency", "get_phase", "get_max_freq", "get_min_freq", "fft", "fftn", "ifft", "ifftn", "qpsk_demod",
+    "rx_frame", "qpsk_dropin_costas_frame", "qpsk_dropin_symbols", "qpsk_dropin_offset_freq",
+    "qpsk_dropin_timing_index",
+]
+
+
+def load():
+    """Load the library; raises QpskError if it has not been built (no fallback of any kind)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise QpskError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback)" % p)
+    L = C.CDLL(p)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    L.qpsk_last_error.restype = C.c_char_p
+    L.qpsk_version.restype = C.c_char_p
+    L.qpsk_params_default.argtypes = [C.POINTER(Params)]
+    L.qpsk_ctx_create.argtypes = [C.POINTER(vp), i32, C.POINTER(Params), vp]
+    L.qpsk_ctx_destroy.argtypes = [vp]
+    L.qpsk_ctx_destroy.restype = None
+    L.qpsk_ctx_sync.argtypes = [vp]
+    L.qpsk_ctx_set_stream.argtypes = [vp, vp]
+    L.qpsk_ctx_cycles.argtypes = [vp]
+    L.qpsk_ctx_nsym.argtypes = [vp]
+    L.qpsk_ctx_get_taps.argtypes = [vp, C.POINTER(f32)]
+    L.qpsk_ctx_get_gains.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
+    L.qpsk_ctx_set_taps.argtypes = [vp, C.POINTER(f32)]
+    L.qpsk_ctx_set_loop.argtypes = [vp, f32, f32, f32, f32]
+    L.qpsk_rx_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.qpsk_rx_batch_bw.argtypes = [vp, vp, i32, C.POINTER(f32), i32, vp, vp, vp, vp]
+    L.qpsk_rrc_fir_batch.argtypes = [vp, vp, vp, vp, i32, i32]
+    L.qpsk_timing_hist_batch.argtypes = [vp, vp, i32, vp]
+    L.qpsk_costas_batch.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.qpsk_fft_batch.argtypes = [vp, vp, vp, i32, i32, i32]
+    L.qpsk_streams_reset.argtypes = [vp, i32, C.c_double]
+    L.qpsk_streams_set_loop_state.argtypes = [vp, C.POINTER(f32)]
+    L.qpsk_streams_get_loop_state.argtypes = [vp, C.POINTER(f32)]
+    L.qpsk_streams_rx_cplx.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.qpsk_streams_rx_pcm.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.qpsk_selftest_sincos_hash.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong)]
+    _LIB = L
+    return L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Modem:
+    """One qpsk_ctx: a configuration (taps, loop gains) bound to one GPU and one HIP stream."""
+
+    def __init__(self, fs=9600.0, rs=2400.0, frame_size=512, rrc_alpha=0.35, loop_bw=np.float32(TAU / 100.0),
+                 min_freq=-1.0, max_freq=1.0, timing_mode=TIMING_HIST, fixed_index=0, device=None, stream="torch"):
+        import torch
+        self.torch = torch
+        self.L = load()
+        if not torch.cuda.is_available():
+            raise QpskError("no GPU visible to torch; libqpsk_hip has no CPU path")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.dev = torch.device("cuda", self.device)
+        self.params = Params(fs, rs, frame_size, rrc_alpha, loop_bw, min_freq, max_freq, timing_mode, fixed_index)
+        if stream == "torch":
+            s = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        elif stream is None:
+            s = None
+        else:
+            s = C.c_void_p(int(stream))
+        h = C.c_void_p()
+        self._check(self.L.qpsk_ctx_create(C.byref(h), self.device, C.byref(self.params), s))
+        self.h = h
+        self.cycles = self.L.qpsk_ctx_cycles(h)
+        self.nsym = self.L.qpsk_ctx_nsym(h)
+        self.frame_size = frame_size
+        self.nstreams = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise QpskError("libqpsk_hip error %d: %s" % (rc, self.L.qpsk_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.qpsk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self.L.qpsk_ctx_sync(self.h))
+
+    # ---- configuration
+    @property
+    def taps(self):
+        t = (C.c_float * NTAPS)()
+        self._check(self.L.qpsk_ctx_get_taps(self.h, t))
+        return np.array(t, np.float32)
+
+    @property
+    def gains(self):
+        a, b = C.c_float(), C.c_float()
+        self._check(self.L.qpsk_ctx_get_gains(self.h, C.byref(a), C.byref(b)))
+        return np.float32(a.value), np.float32(b.value)
+
+    def set_taps(self, taps):
+        t = (C.c_float * NTAPS)(*[float(x) for x in taps])
+        self._check(self.L.qpsk_ctx_set_taps(self.h, t))
+
+    def set_loop(self, alpha, beta, min_freq, max_freq):
+        self._check(self.L.qpsk_ctx_set_loop(self.h, alpha, beta, min_freq, max_freq))
+
+    # ---- helpers
+    def _dev(self, a, dtype):
+        t = self.torch
+        if isinstance(a, np.ndarray):
+            a = t.from_numpy(np.ascontiguousarray(a))
+        a = a.to(self.dev)
+        assert a.dtype == dtype, (a.dtype, dtype)
+        return a.contiguous()
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.dev)
+
+    # ---- the hot path
+    def rx_batch(self, frames, want_costas=False, out=None):
+        """frames: (F, frame_size, 2) float32 (numpy or torch).  Returns dict of torch tensors."""
+        t = self.torch
+        x = self._dev(frames, t.float32)
+        F = x.shape[0]
+        assert x.shape[1] == self.frame_size and x.shape[2] == 2
+        o = out or dict(sym=self.empty((F, self.nsym), t.uint8), freq=self.empty((F,), t.float32),
+                        phase=self.empty((F,), t.float32), index=self.empty((F,), t.int32),
+                        hz=self.empty((F,), t.float32),
+                        costas=self.empty((F, self.nsym, 2), t.float32) if want_costas else None)
+        self._check(self.L.qpsk_rx_batch(self.h, _ptr(x), F, _ptr(o["sym"]), _ptr(o["freq"]), _ptr(o["phase"]),
+                                         _ptr(o.get("costas")), _ptr(o.get("index")), _ptr(o.get("hz"))))
+        return o
+
+    def rx_batch_raw(self, x, F, sym, freq, phase):
+        """No allocation, no checks: the call bench.py times."""
+        rc = self.L.qpsk_rx_batch(self.h, _ptr(x), F, _ptr(sym), _ptr(freq), _ptr(phase), None, None, None)
+        if rc:
+            self._check(rc)
+
+    def rx_batch_bw(self, frames, loop_bws):
+        t = self.torch
+        x = self._dev(frames, t.float32)
+        F, B = x.shape[0], len(loop_bws)
+        bws = (C.c_float * B)(*[float(b) for b in loop_bws])
+        o = dict(sym=self.empty((F, B, self.nsym), t.uint8), freq=self.empty((F, B), t.float32),
+                 phase=self.empty((F, B), t.float32), index=self.empty((F,), t.int32))
+        self._check(self.L.qpsk_rx_batch_bw(self.h, _ptr(x), F, bws, B, _ptr(o["sym"]), _ptr(o["freq"]),
+                                            _ptr(o["phase"]), _ptr(o["index"])))
+        return o
+
+    # ---- stages
+    def rrc_fir(self, x, memory=None):
+        """x: (F, n, 2); memory: (F, 127, 2) updated in place (torch tensor) or None."""
+        t = self.torch
+        x = self._dev(x, t.float32)
+        y = t.empty_like(x)
+        self._check(self.L.qpsk_rrc_fir_batch(self.h, _ptr(memory), _ptr(x), _ptr(y), x.shape[0], x.shape[1]))
+        return y
+
+    def timing_hist(self, filtered):
+        t = self.torch
+        y = self._dev(filtered, t.float32)
+        idx = self.empty((y.shape[0],), t.int32)
+        self._check(self.L.qpsk_timing_hist_batch(self.h, _ptr(y), y.shape[0], _ptr(idx)))
+        return idx
+
+    def costas(self, d, state=None, want_costas=True):
+        t = self.torch
+        d = self._dev(d, t.float32)
+        F, N = d.shape[0], d.shape[1]
+        sym = self.empty((F, N), t.uint8)
+        z = self.empty((F, N, 2), t.float32) if want_costas else None
+        self._check(self.L.qpsk_costas_batch(self.h, _ptr(d), F, N, _ptr(state), _ptr(sym), _ptr(z)))
+        return sym, z
+
+    def fft(self, x, inverse=False):
+        """x: (B, n) complex128 numpy/torch -> torch complex128"""
+        t = self.torch
+        if isinstance(x, np.ndarray):
+            x = t.from_numpy(np.ascontiguousarray(x, dtype=np.complex128))
+        x = x.to(self.dev).contiguous()
+        out = t.empty_like(x)
+        self._check(self.L.qpsk_fft_batch(self.h, _ptr(x), _ptr(out), x.shape[0], x.shape[1], int(inverse)))
+        return out
+
+    # ---- streams
+    def streams_reset(self, nstreams, mixer_hz=1500.0):
+        self._check(self.L.qpsk_streams_reset(self.h, nstreams, mixer_hz))
+        self.nstreams = nstreams
+
+    def _stream_out(self, want_costas):
+        t, n = self.torch, self.nstreams
+        return dict(sym=self.empty((n, self.nsym), t.uint8), freq=self.empty((n,), t.float32),
+                    phase=self.empty((n,), t.float32), index=self.empty((n,), t.int32),
+                    costas=self.empty((n, self.nsym, 2), t.float32) if want_costas else None)
+
+    def streams_rx_cplx(self, blocks, want_costas=True):
+        x = self._dev(blocks, self.torch.float32)
+        o = self._stream_out(want_costas)
+        self._check(self.L.qpsk_streams_rx_cplx(self.h, _ptr(x), _ptr(o["sym"]), _ptr(o["freq"]), _ptr(o["phase"]),
+                                                _ptr(o["costas"]), _ptr(o["index"])))
+        return o
+
+    def streams_rx_pcm(self, pcm, want_costas=True):
+        x = self._dev(pcm, self.torch.int16)
+        o = self._stream_out(want_costas)
+        self._check(self.L.qpsk_streams_rx_pcm(self.h, _ptr(x), _ptr(o["sym"]), _ptr(o["freq"]), _ptr(o["phase"]),
+                                               _ptr(o["costas"]), _ptr(o["index"])))
+        return o
+
+    def streams_loop_state(self):
+        a = (C.c_float * (2 * self.nstreams))()
+        self._check(self.L.qpsk_streams_get_loop_state(self.h, a))
+        return np.array(a, np.float32).reshape(-1, 2)
+
+    def sincos_hash(self, first, count):
+        h = C.c_ulonglong()
+        self._check(self.L.qpsk_selftest_sincos_hash(self.h, first, count, C.byref(h)))
+        return h.value

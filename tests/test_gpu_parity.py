@@ -1,0 +1,281 @@
+"""Parity of the HIP path (through the C ABI, include/qpsk_hip.h) with the CPU oracle on the same
+inputs.  Bar: symbols, costas_frame, loop phase/frequency and every intermediate BIT-EXACT
+(the 1e-5 relative tolerance BASELINE.json allows for phase/frequency is not used: 0 is achieved)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from oracle.pyoracle import TAU, TIMING_FIXED, TIMING_HIST
+from sigutil import bits_equal, make_frames, random_frames
+
+pytestmark = pytest.mark.gpu
+BW = np.float32(TAU / 100.0)
+
+
+def modem(**kw):
+    import qpsk_amd
+    return qpsk_amd.Modem(**kw)
+
+
+def cpu(t):
+    return t.cpu().numpy()
+
+
+def assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz", "costas")):
+    for k in keys:
+        if k in want and got.get(k) is not None:
+            g = cpu(got[k])
+            assert bits_equal(g, want[k].astype(g.dtype)), "%s differs (%d mismatching elements)" % (
+                k, int(np.sum(g.reshape(-1).view(np.uint8) != want[k].astype(g.dtype).reshape(-1).view(np.uint8))))
+
+
+# ------------------------------------------------------------------ sin/cos on the device
+def test_device_sincos_equals_oracle_exhaustive_costas_domain(oracle):
+    """every float in [-2pi, 2pi] (2.17e9 arguments) through the device routine, hashed, against the
+    same hash of the oracle's restatement (itself pinned to libm exhaustively)"""
+    import subprocess, tempfile
+    m = modem()
+    top = np.float32(6.2831855).view(np.uint32)
+    dev = m.sincos_hash(0, int(top) + 1)
+    src = r'''
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+#include "oracle_sincosf.h"
+int main(void){ uint32_t top=%uu; unsigned long long h=0;
+#pragma omp parallel for reduction(+:h) schedule(static,65536)
+ for(uint32_t u=0;u<=top;u++) for(int sg=0;sg<2;sg++){ uint32_t b=u|((uint32_t)sg<<31); float y,s,c; memcpy(&y,&b,4);
+  oracle_sincosf(y,&s,&c); uint32_t sb,cb; memcpy(&sb,&s,4); memcpy(&cb,&c,4);
+  unsigned long long v=((unsigned long long)sb<<32)|cb; v^=(unsigned long long)b*0x9E3779B97F4A7C15ull; v*=0xD6E8FEB86659FD93ull; v^=v>>32; h+=v; }
+ printf("%%llu\n",h); return 0; }''' % int(top)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "h.c"), "w").write(src)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(root, "oracle"),
+                               os.path.join(d, "h.c"), "-o", os.path.join(d, "h"), "-lm"])
+        host = int(subprocess.check_output([os.path.join(d, "h")]).decode())
+    assert dev == host
+
+
+# ------------------------------------------------------------------ configuration numbers
+def test_taps_and_gains_equal_oracle(oracle):
+    for fs, rs, a in [(9600.0, 2400.0, .35), (19200.0, 2400.0, .35), (9600.0, 1200.0, .5)]:
+        m = modem(fs=fs, rs=rs, frame_size=int(fs / rs) * 64, rrc_alpha=a)
+        assert bits_equal(m.taps, oracle.rrc_make(fs, rs, np.float32(a)))
+        from oracle.pyoracle import Costas
+        c = Costas()
+        oracle.lib.qo_costas_create(C.byref(c), BW, -1.0, 1.0)
+        al, be = m.gains
+        assert al == np.float32(c.alpha) and be == np.float32(c.beta)
+
+
+# ------------------------------------------------------------------ the hot path
+@pytest.mark.parametrize("fs,rs,L,F", [(19200.0, 2400.0, 1024, 37), (19200.0, 2400.0, 16384, 24), (9600.0, 2400.0, 512, 70),
+                                       (9600.0, 1200.0, 4096, 9), (19200.0, 2400.0, 8, 3), (19200.0, 2400.0, 136, 5)])
+@pytest.mark.parametrize("index", [0, 3, 7])
+def test_rx_batch_fixed_index(oracle, fs, rs, L, F, index):
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=index)
+    x, _ = make_frames(F, L, m.cycles, m.taps, fs, offset_hz=50.0, base_seed=L + index, noise=0.02)
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=index, want_costas=True)
+    got = m.rx_batch(x, want_costas=True)
+    m.sync()
+    assert_batch_equal(got, want)
+
+
+@pytest.mark.parametrize("fs,rs,L,F", [(19200.0, 2400.0, 1024, 40), (19200.0, 2400.0, 16384, 6), (9600.0, 2400.0, 512, 33),
+                                       (9600.0, 1200.0, 4096, 5)])
+def test_rx_batch_reference_timing(oracle, fs, rs, L, F):
+    """the reference's own histogram timing estimate in front of the fused kernel"""
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_HIST)
+    x, _ = make_frames(F, L, m.cycles, m.taps, fs, offset_hz=-35.0, base_seed=L, noise=0.05)
+    x[-1] = random_frames(1, L, seed=1)[0]      # not a modem signal
+    x[-2] = 0.0                                  # all-zero block -> index 1 (Q4)
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_HIST, want_costas=True)
+    assert want["index"][-2] == 1
+    got = m.rx_batch(x, want_costas=True)
+    m.sync()
+    assert_batch_equal(got, want)
+
+
+def test_rx_batch_tilings_agree(oracle, monkeypatch):
+    """results do not depend on how frames are grouped into workgroups / chunks"""
+    fs, rs, L, F = 19200.0, 2400.0, 2048, 50
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=4)
+    x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=3)
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=4, want_costas=True)
+    for G, S in [(1, 8), (3, 24), (16, 32), (64, 8), (7, 64)]:
+        monkeypatch.setenv("QPSK_FUSED_G", str(G))
+        monkeypatch.setenv("QPSK_FUSED_S", str(S))
+        got = m.rx_batch(x, want_costas=True)
+        m.sync()
+        assert_batch_equal(got, want)
+
+
+def test_rx_batch_golden_vectors():
+    """straight against the reference's own outputs (tests/golden, generated from the reference)"""
+    for name in ("c1small", "c1", "c5small_bw200"):
+        g = golden("independent_%s.npz" % name)
+        m = modem(fs=float(g["fs"]), rs=float(g["rs"]), frame_size=int(g["frame_size"]),
+                  loop_bw=np.float32(g["loop_bw"]), timing_mode=TIMING_HIST)
+        got = m.rx_batch(g["x"], want_costas=True)
+        m.sync()
+        assert_batch_equal(got, {k: g[k] for k in ("sym", "costas", "phase", "freq", "hz", "index")})
+
+
+def test_extreme_inputs(oracle):
+    """large amplitudes (several phase wraps per step), tiny amplitudes (denormal products), clamp active"""
+    fs, rs, L = 19200.0, 2400.0, 1024
+    for scale, lo, hi, bw in [(50.0, -1.0, 1.0, BW), (1e-20, -1.0, 1.0, BW), (1.0, -0.01, 0.005, BW),
+                              (3.0, -6.0, 6.0, np.float32(0.9)), (1e-38, -1.0, 1.0, BW)]:
+        m = modem(fs=fs, rs=rs, frame_size=L, loop_bw=bw, min_freq=lo, max_freq=hi, timing_mode=TIMING_FIXED, fixed_index=2)
+        x = random_frames(20, L, seed=int(abs(np.log10(scale)) + 1), scale=scale)
+        want = oracle.rx_batch(x, fs, rs, loop_bw=bw, min_freq=lo, max_freq=hi, timing_mode=TIMING_FIXED, fixed_index=2, want_costas=True)
+        got = m.rx_batch(x, want_costas=True)
+        m.sync()
+        assert_batch_equal(got, want)
+
+
+def test_loop_bandwidth_sweep(oracle):
+    """README.md:12: loop bandwidth TAU/100 .. TAU/200, several loops sharing one FIR pass (config 5)"""
+    fs, rs, L, F = 9600.0, 1200.0, 8192, 7
+    bws = [np.float32(TAU / d) for d in range(100, 201, 10)]
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=4)
+    x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=12.0, base_seed=9, noise=0.03)
+    want = oracle.rx_batch_bw(x, fs, rs, bws, timing_mode=TIMING_FIXED, fixed_index=4)
+    got = m.rx_batch_bw(x, bws)
+    m.sync()
+    assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
+    # and the single-loop entry still uses the context's own gains afterwards
+    one = m.rx_batch(x)
+    m.sync()
+    assert bits_equal(cpu(one["sym"]), want["sym"][:, 0]) and bits_equal(cpu(one["freq"]), want["freq"][:, 0])
+
+
+# ------------------------------------------------------------------ stages
+def test_rrc_fir_batch_with_delay_lines(oracle):
+    import torch
+    m = modem(fs=19200.0, rs=2400.0, frame_size=1024)
+    rng = np.random.default_rng(2)
+    for n in (1, 5, 126, 127, 128, 1000, 1024, 4097):
+        F = 5
+        x = rng.standard_normal((F, n, 2)).astype(np.float32)
+        mem = rng.standard_normal((F, 127, 2)).astype(np.float32)
+        d_mem = torch.from_numpy(mem.copy()).cuda()
+        y = m.rrc_fir(x, d_mem)
+        m.sync()
+        for f in range(F):
+            ym, mm = x[f].copy(), mem[f].copy()
+            oracle.rrc_fir(m.taps, mm, ym)
+            assert bits_equal(cpu(y[f]), ym), (n, f)
+            assert bits_equal(cpu(d_mem[f]), mm), (n, f)
+    # zero history, no write-back
+    x = rng.standard_normal((3, 300, 2)).astype(np.float32)
+    y = m.rrc_fir(x, None)
+    m.sync()
+    for f in range(3):
+        ym, mm = x[f].copy(), np.zeros((127, 2), np.float32)
+        oracle.rrc_fir(m.taps, mm, ym)
+        assert bits_equal(cpu(y[f]), ym)
+
+
+def test_fir_golden():
+    import torch
+    g = golden("fir.npz")
+    m = modem()
+    m.set_taps(g["taps"])
+    d_mem = torch.from_numpy(g["mem0"].copy()[None]).cuda()
+    for i in range(6):
+        y = m.rrc_fir(g["x%d" % i][None], d_mem)
+        m.sync()
+        assert bits_equal(cpu(y[0]), g["y%d" % i]) and bits_equal(cpu(d_mem[0]), g["m%d" % i])
+
+
+@pytest.mark.parametrize("cycles,L", [(8, 1024), (4, 512), (5, 1000), (8, 16384)])
+def test_timing_histogram(oracle, cycles, L):
+    rs = 2400.0
+    m = modem(fs=rs * cycles, rs=rs, frame_size=L)
+    x, _ = make_frames(30, L, cycles, m.taps, rs * cycles, noise=0.1, base_seed=cycles)
+    x[0] = 0.0
+    x[1] = random_frames(1, L, seed=5)[0]
+    idx = cpu(m.timing_hist(x))
+    for f in range(x.shape[0]):
+        assert idx[f] == oracle.timing_index(x[f], cycles), f
+
+
+def test_costas_batch_with_state(oracle):
+    import torch
+    from oracle.pyoracle import Costas
+    m = modem(fs=19200.0, rs=2400.0, frame_size=1024)
+    rng = np.random.default_rng(3)
+    F, N = 70, 300
+    d = rng.standard_normal((F, N, 2)).astype(np.float32)
+    st0 = np.stack([rng.uniform(-6, 6, F), rng.uniform(-1, 1, F)], -1).astype(np.float32)
+    st0[0] = [-0.0, 0.0]
+    st0[1] = [6.2831855, 1.0]
+    st = torch.from_numpy(st0.copy()).cuda()
+    sym, z = m.costas(d, st)
+    m.sync()
+    for f in range(F):
+        c = Costas()
+        oracle.lib.qo_costas_create(C.byref(c), BW, -1.0, 1.0)
+        c.phase, c.freq = float(st0[f, 0]), float(st0[f, 1])
+        zr, zi = C.c_float(), C.c_float()
+        for i in range(N):
+            s = oracle.lib.qo_costas_step(C.byref(c), float(d[f, i, 0]), float(d[f, i, 1]), C.byref(zr), C.byref(zi))
+            assert s == int(sym[f, i])
+            assert np.float32(zr.value).view(np.uint32) == cpu(z[f, i, 0]).view(np.uint32)
+            assert np.float32(zi.value).view(np.uint32) == cpu(z[f, i, 1]).view(np.uint32)
+        assert bits_equal(cpu(st[f]), np.array([c.phase, c.freq], np.float32))
+
+
+def test_fft_batch(oracle):
+    rng = np.random.default_rng(4)
+    m = modem()
+    for n in (1, 2, 8, 512, 2048, 8192):
+        x = rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))
+        X = cpu(m.fft(x))
+        Xi = cpu(m.fft(x, inverse=True))
+        m.sync()
+        for b in range(5):
+            assert bits_equal(X[b], oracle.fftn(x[b])), n       # same host libm builds both twiddle sets
+            assert bits_equal(Xi[b], oracle.ifftn(x[b])), n
+    g = golden("fft_bits.npz")
+    np.testing.assert_allclose(cpu(m.fft(g["x512"][None]))[0], g["fft512"], rtol=0, atol=1e-15)
+    assert np.all(cpu(m.fft(np.eye(1, 512, dtype=np.complex128)))[0] == 2.0 ** -9)
+
+
+# ------------------------------------------------------------------ streams (consecutive rx_frame calls)
+@pytest.mark.parametrize("name", ["shipped", "c1small"])
+def test_streams_pcm_golden(name):
+    g = golden("stream_pcm_%s.npz" % name)
+    L = int(g["frame_size"])
+    m = modem(fs=float(g["fs"]), rs=float(g["rs"]), frame_size=L, loop_bw=np.float32(g["loop_bw"]))
+    m.streams_reset(3, 1500.0)
+    for k in range(g["sym"].shape[0]):
+        blk = np.repeat(g["pcm"][k * L:(k + 1) * L][None], 3, 0)
+        o = m.streams_rx_pcm(blk)
+        m.sync()
+        for s in range(3):
+            assert cpu(o["index"])[s] == g["index"][k]
+            assert bits_equal(cpu(o["sym"][s]), g["sym"][k]) and bits_equal(cpu(o["costas"][s]), g["costas"][k])
+            assert cpu(o["phase"])[s] == g["phase"][k] and cpu(o["freq"])[s] == g["freq"][k]
+
+
+def test_streams_cplx_vs_oracle(oracle):
+    fs, rs, L, S = 19200.0, 2400.0, 1024, 9
+    m = modem(fs=fs, rs=rs, frame_size=L)
+    m.streams_reset(S)
+    om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
+    x, _ = make_frames(S, L * 5, 8, m.taps, fs, offset_hz=30.0, base_seed=17, noise=0.02)
+    for k in range(5):
+        blk = np.ascontiguousarray(x[:, k * L:(k + 1) * L])
+        o = m.streams_rx_cplx(blk)
+        m.sync()
+        for s in range(S):
+            om[s].rx_cplx(blk[s])
+            assert cpu(o["index"])[s] == om[s].index
+            assert bits_equal(cpu(o["sym"][s]), om[s].symbols) and bits_equal(cpu(o["costas"][s]), om[s].costas_frame)
+            assert cpu(o["phase"])[s] == om[s].phase and cpu(o["freq"])[s] == om[s].freq

@@ -1,0 +1,118 @@
+"""The oracle against the reference ITSELF (oracle/_ref = /root/reference compiled untouched, see
+oracle/Makefile).  Only possible in the build container; skipped where oracle/_ref is absent (GPU box),
+where tests/test_oracle_golden.py pins the same functions through the committed fixtures instead."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import TAU, TIMING_HIST, Reference, ref_available
+from sigutil import bits_equal, make_frames, random_frames
+
+pytestmark = pytest.mark.skipif(not ref_available("c1small"), reason="oracle/_ref not built (no /root/reference here)")
+BW = np.float32(TAU / 100.0)
+
+
+@pytest.mark.parametrize("name", ["shipped", "c1small", "c5small"])
+def test_streaming_pcm_matches_reference(oracle, name):
+    ref = Reference(name)
+    ref.reset(BW, -1.0, 1.0, .35, 1550.0, 1500.0)
+    rng = np.random.default_rng(100)
+    L, N = ref.frame_size, ref.nsym
+    nblk = 5
+    bits = rng.integers(0, 2, size=2 * N * nblk).astype(np.int32)
+    pcm = np.concatenate([ref.tx_symbols(bits[2 * k:2 * min(k + 256, N * nblk)]) for k in range(0, N * nblk, 256)])
+    # the oracle's transmitter restatement (qpsk.c:225-285) produces the same PCM
+    tx = oracle.tx(ref.fs, ref.rs, np.float32(.35), 1550.0)
+    pcm_o = np.concatenate([tx.symbols(bits[2 * k:2 * min(k + 256, N * nblk)]) for k in range(0, N * nblk, 256)])
+    assert bits_equal(pcm, pcm_o)
+    m = oracle.modem(ref.fs, ref.rs, L, loop_bw=BW)
+    m.set_mixer(ref.mixer)
+    for k in range(nblk):
+        blk = pcm[k * L:(k + 1) * L]
+        ref.rx_pcm(blk)
+        m.rx_pcm(blk)
+        assert bits_equal(ref.input_frame, m.input_frame), "filtered block %d" % k
+        last = 2 * N if ref.cycles >= 8 else 2 * N - 1  # Q5: the last pick is undefined in the reference at CYCLES<8
+        assert bits_equal(ref.decimated[:last], m.decimated[:last])
+        assert bits_equal(ref.costas_frame, m.costas_frame) and bits_equal(ref.symbols, m.symbols)
+        assert ref.phase == m.phase and ref.freq == m.freq and ref.offset_hz == m.offset_hz
+        assert bits_equal(ref.rx_filter, m.rx_filter) and bits_equal(ref.mixer, m.mixer)
+        if ref.cycles < 8:
+            d = ref.decimated
+            d[2 * N - 1] = m.decimated[2 * N - 1]  # defined-as-zero value
+            ref.set_decimated(d)
+
+
+@pytest.mark.parametrize("name,kind", [("c1small", "modem"), ("c1small", "noise"), ("c5small", "modem"), ("c1", "modem")])
+def test_independent_frames_match_reference(oracle, name, kind):
+    ref = Reference(name)
+    ref.reset()
+    L = ref.frame_size
+    F = 2 if name == "c1" else 6
+    if kind == "modem":
+        x, _ = make_frames(F, L, ref.cycles, ref.taps(), ref.fs, offset_hz=40.0, base_seed=7, noise=0.05)
+    else:
+        x = random_frames(F, L, seed=3, scale=0.7)
+    o = oracle.rx_batch(x, ref.fs, ref.rs, loop_bw=BW, timing_mode=TIMING_HIST, want_costas=True)
+    for f in range(F):
+        r = ref.independent_frame(x[f], loop_bw=BW)
+        assert bits_equal(r["sym"], o["sym"][f]) and bits_equal(r["costas"], o["costas"][f])
+        assert r["phase"] == o["phase"][f] and r["freq"] == o["freq"][f] and r["hz"] == o["hz"][f]
+
+
+def test_loop_bandwidth_sweep_matches_reference(oracle):
+    ref = Reference("c5small")
+    ref.reset()
+    x, _ = make_frames(2, ref.frame_size, ref.cycles, ref.taps(), ref.fs, offset_hz=20.0, base_seed=5)
+    bws = [np.float32(TAU / d) for d in (100.0, 150.0, 200.0)]
+    o = oracle.rx_batch_bw(x, ref.fs, ref.rs, bws, timing_mode=TIMING_HIST)
+    for f in range(2):
+        for b, bw in enumerate(bws):
+            r = ref.independent_frame(x[f], loop_bw=bw)
+            assert bits_equal(r["sym"], o["sym"][f, b]) and r["phase"] == o["phase"][f, b] and r["freq"] == o["freq"][f, b]
+
+
+def test_costas_scalar_api_matches_reference(oracle):
+    from oracle.pyoracle import Costas
+    import ctypes as C
+    ref = Reference("shipped")
+    ref.reset()
+    rng = np.random.default_rng(8)
+    for bw, lo, hi in [(BW, -1.0, 1.0), (np.float32(TAU / 200), -0.2, 0.3), (np.float32(0.5), -5.0, 5.0)]:
+        ref.lib.create_control_loop(bw, lo, hi)
+        c = Costas()
+        oracle.lib.qo_costas_create(C.byref(c), bw, lo, hi)
+        for _ in range(200):
+            e = np.float32(rng.standard_normal() * 3)
+            ref.lib.advance_loop(e); ref.lib.phase_wrap(); ref.lib.frequency_limit()
+            oracle.lib.qo_advance_loop(C.byref(c), e); oracle.lib.qo_phase_wrap(C.byref(c)); oracle.lib.qo_frequency_limit(C.byref(c))
+            st = ref.costas_state
+            mine = np.array([c.phase, c.freq, c.max_freq, c.min_freq, c.damping, c.loop_bw, c.alpha, c.beta], np.float32)
+            assert bits_equal(st, mine)
+        # setters, including the ones whose range checks are dead code (costas_loop.c:79-115)
+        for name, v in [("set_alpha", 7.0), ("set_beta", -3.0), ("set_loop_bandwidth", -0.1), ("set_damping_factor", -1.0),
+                        ("set_frequency", 99.0), ("set_frequency", -99.0), ("set_phase", 20.0), ("set_phase", -20.0)]:
+            getattr(ref.lib, name)(v)
+            getattr(oracle.lib, "qo_" + name)(C.byref(c), v)
+            mine = np.array([c.phase, c.freq, c.max_freq, c.min_freq, c.damping, c.loop_bw, c.alpha, c.beta], np.float32)
+            assert bits_equal(ref.costas_state, mine), name
+
+
+def test_fft_matches_reference(oracle):
+    ref = Reference("shipped")
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 4, 16, 512, 1024):
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        assert bits_equal(ref.fftn(x), oracle.fftn(x)), n
+        assert bits_equal(ref.ifftn(x), oracle.ifftn(x)), n
+
+
+def test_bit_stages_match_reference(oracle):
+    ref = Reference("shipped")
+    rng = np.random.default_rng(6)
+    for n in (1, 2, 8, 22, 40, 43):
+        d = rng.integers(0, 256, size=n).astype(np.uint8)
+        assert bits_equal(ref.interleave(d, 0), oracle.interleave(d, 0)), n
+        assert bits_equal(ref.interleave(d, 1), oracle.interleave(d, 1)), n
+        assert ref.crc16(d.tobytes()) == oracle.crc16(d.tobytes())
+    s = rng.integers(0, 4, size=300).astype(np.uint8)
+    assert bits_equal(ref.scramble_stream(s, 0), oracle.scramble_stream(s))
