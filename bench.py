@@ -38,8 +38,7 @@ def synth_frames_gpu(torch, dev, nframes, taps, seed, offset_hz=50.0):
     g.manual_seed(seed)
     nsym = L // CYCLES
     out = torch.empty((nframes, L, 2), dtype=torch.float32, device=dev)
-    const = torch.tensor([[1, 0], [0, 1], [0, -1], [-1, 0]], dtype=torch.float32, device=dev)  # qpsk.c:58-63
-    k = torch.from_numpy(np.asarray(taps, np.float32)[::-1].copy()).to(dev).view(1, 1, -1) * 1.85
+    k =torch.from_numpy(np.asarray(taps, np.float32)[::-1].copy()).to(dev).view(1, 1, -1) * 1.85
     n = torch.arange(L, device=dev, dtype=torch.float64)
     ang = 2.0 * np.pi * offset_hz * n / FS
     cr, ci = torch.cos(ang).float(), torch.sin(ang).float()
@@ -48,7 +47,9 @@ def synth_frames_gpu(torch, dev, nframes, taps, seed, offset_hz=50.0):
         f1 = min(nframes, f0 + chunk)
         s = torch.randint(0, 4, (f1 - f0, nsym), generator=g, device=dev)
         up = torch.zeros((f1 - f0, 2, L), dtype=torch.float32, device=dev)
-        up[:, :, ::CYCLES] = const[s].permute(0, 2, 1)
+        # Gray-coded constellation 0:(1,0) 1:(0,1) 2:(0,-1) 3:(-1,0)  (qpsk.c:58-63)
+        up[:, 0, ::CYCLES] = (s == 0).float() - (s == 3).float()
+        up[:, 1, ::CYCLES] = (s == 1).float() - (s == 2).float()
         y = torch.nn.functional.conv1d(torch.nn.functional.pad(up.reshape(-1, 1, L), (126, 0)), k).reshape(f1 - f0, 2, L)
         out[f0:f1, :, 0] = y[:, 0] * cr - y[:, 1] * ci
         out[f0:f1, :, 1] = y[:, 0] * ci + y[:, 1] * cr
@@ -89,6 +90,11 @@ def cpu_baseline(x_host, taps):
     return out
 
 
+def note(msg):
+    if os.environ.get("QPSK_BENCH_VERBOSE"):
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,7 +130,10 @@ def main():
     m = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX,
                        device=local)
     # rank r owns frames [r*F, (r+1)*F) of the global batch (seeded by rank): independent shards, no exchange
+    note("context ready, generating %d frames" % F)
     x = synth_frames_gpu(torch, dev, F, m.taps, seed=1000 + rank)
+    torch.cuda.synchronize()
+    note("frames ready")
     sym = torch.empty((F, m.nsym), dtype=torch.uint8, device=dev)
     freq = torch.empty((F,), dtype=torch.float32, device=dev)
     phase = torch.empty((F,), dtype=torch.float32, device=dev)
@@ -136,6 +145,7 @@ def main():
     for _ in range(args.warmup):
         m.rx_batch_raw(x, F, sym, freq, phase)
     torch.cuda.synchronize()
+    note("warmup done")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

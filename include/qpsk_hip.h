@@ -80,7 +80,8 @@ int qpsk_device_count(void);
 /* main()'s defaults: FS 9600, RS 2400, FRAME_SIZE 512, alpha .35, loop TAU/100, clamp +-1 (qpsk.c:302,308) */
 void qpsk_params_default(qpsk_params *p);
 
-/* device < 0: current HIP device.  stream: a hipStream_t to run on, or NULL for a private one. */
+/* device < 0: current HIP device.  stream: the hipStream_t every call of this context is enqueued on;
+ * NULL = the HIP default stream (the caller owns the stream and keeps it alive). */
 int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stream);
 void qpsk_ctx_destroy(qpsk_ctx *ctx);
 int qpsk_ctx_sync(qpsk_ctx *ctx);

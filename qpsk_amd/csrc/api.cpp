@@ -53,8 +53,7 @@ struct DevBuf {
 
 struct qpsk_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
+    hipStream_t stream = nullptr; /* caller's stream; nullptr = default stream */
     qpsk_params prm{};
     int cycles = 0, nsym = 0;
     float taps[QPSK_NTAPS];
@@ -176,13 +175,7 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
     c->prm = *p;
     c->cycles = cycles;
     c->nsym = p->frame_size / cycles;
-    if (stream) {
-        c->stream = (hipStream_t)stream;
-    } else {
-        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (se != hipSuccess) { delete c; return fail(QPSK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
-        c->own_stream = true;
-    }
+    c->stream = (hipStream_t)stream; /* NULL = the HIP default stream, like every HIP library */
     qpsk_host_rrc_taps((float)p->fs, (float)p->rs, p->rrc_alpha, c->taps); /* rrc_make(FS, RS, alpha), qpsk.c:308 */
     c->damping = sqrtf(2.0f) / 2.0f;                                        /* costas_loop.c:38 */
     qpsk_host_loop_gains(c->damping, p->loop_bw, &c->alpha, &c->beta);
@@ -210,7 +203,7 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->stream);
     hipFree(c->d_taps);
     hipFree(c->d_gains);
     hipFree(c->index.p);
@@ -218,7 +211,6 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
     hipFree(c->mixed.p);
     for (auto &kv : c->twiddles) hipFree(kv.second);
     free_streams(c);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -235,13 +227,7 @@ int qpsk_ctx_set_stream(qpsk_ctx *c, void *stream)
     if (!c) return fail(QPSK_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->own_stream) { hipStreamDestroy(c->stream); c->own_stream = false; }
-    if (stream) {
-        c->stream = (hipStream_t)stream;
-    } else {
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
+    c->stream = (hipStream_t)stream;
     return QPSK_OK;
 }
 
