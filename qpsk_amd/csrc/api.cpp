@@ -61,6 +61,7 @@ struct qpsk_ctx {
     float min_freq = 0.f, max_freq = 0.f;
     float *d_taps = nullptr;     /* 128 floats */
     float *d_gains = nullptr;    /* MAX_BW x (alpha, beta) */
+    int *d_status = nullptr;     /* set by a kernel whose internal pipeline gave up (bounded spins) */
     std::vector<float> h_gains;
     DevBuf index, filtered, mixed;
     std::map<int, double *> twiddles;
@@ -170,6 +171,7 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
 
     HIP_TRY(hipSetDevice(device));
     KERNEL_TRY(prepare_kernels());
+    KERNEL_TRY(prepare_pipe_kernel());
     qpsk_ctx *c = new qpsk_ctx();
     c->device = device;
     c->prm = *p;
@@ -182,7 +184,9 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
     c->min_freq = p->min_freq;
     c->max_freq = p->max_freq;
     if (hipMalloc((void **)&c->d_taps, 128 * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&c->d_gains, MAX_BW * 2 * sizeof(float)) != hipSuccess) {
+        hipMalloc((void **)&c->d_gains, MAX_BW * 2 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&c->d_status, sizeof(int)) != hipSuccess ||
+        hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
         qpsk_ctx_destroy(c);
         return fail(QPSK_ERR_ALLOC, "hipMalloc of configuration buffers failed");
     }
@@ -206,6 +210,7 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
     hipStreamSynchronize(c->stream);
     hipFree(c->d_taps);
     hipFree(c->d_gains);
+    hipFree(c->d_status);
     hipFree(c->index.p);
     hipFree(c->filtered.p);
     hipFree(c->mixed.p);
@@ -219,6 +224,13 @@ int qpsk_ctx_sync(qpsk_ctx *c)
     if (!c) return fail(QPSK_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    /* a kernel whose in-LDS producer/consumer pipeline exhausted its bounded spins reports it here */
+    int st = 0;
+    HIP_TRY(hipMemcpy(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
+    if (st != 0) {
+        HIP_TRY(hipMemset(c->d_status, 0, sizeof(int)));
+        return fail(QPSK_ERR_HIP, "rx_fused_pipe_kernel: pipeline wait timed out (status %d); results of the last calls are invalid", st);
+    }
     return QPSK_OK;
 }
 
@@ -340,7 +352,22 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
     a.phase = d_phase;
     a.costas = reinterpret_cast<float2 *>(d_costas);
     a.hz = d_hz;
-    KERNEL_TRY(launch_rx_fused(a, c->stream));
+    /* the pipeline kernel (rx_fused.hip) is built for CYCLES = 8, 16-byte aligned frames and an index
+     * below CYCLES; everything else takes the generic chunked kernel (kernels.hip) */
+    const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 &&
+                         ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames_per_wave() <= 64 &&
+                         !env_int("QPSK_FUSED_GENERIC", 0);
+    if (pipe_ok) {
+        int nf = (nframes + 256 * pipe_frames_per_wave() - 1) / (256 * pipe_frames_per_wave());
+        if (nf > pipe_max_nf()) nf = pipe_max_nf();
+        nf = env_int("QPSK_PIPE_NF", nf);
+        if (nf < 1) nf = 1;
+        if (nf > pipe_max_nf()) nf = pipe_max_nf();
+        while (nf > 1 && nf * pipe_frames_per_wave() * nbw > 64) nf--;
+        KERNEL_TRY(launch_rx_fused_pipe(a, nf, c->d_status, c->stream));
+    } else {
+        KERNEL_TRY(launch_rx_fused(a, c->stream));
+    }
     if (d_index) {
         if (idx)
             HIP_TRY(hipMemcpyAsync(d_index, idx, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToDevice, c->stream));

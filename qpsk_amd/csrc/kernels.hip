@@ -115,7 +115,7 @@ rx_fused_kernel(FusedArgs a)
             const int cnt = min(S, N - sym0);
             const float2 *dl = ds + (size_t)lane_g * S;
             for (int j = 0; j < cnt; j++) {
-                const float2 z = costas_step(st, lg, dl[j]);
+                const float2 z = (c == 0 && j == 0) ? costas_step<true>(st, lg, dl[j]) : costas_step<false>(st, lg, dl[j]);
                 ss[(size_t)tid * S + j] = (uint8_t)slicer(z);
                 if (a.costas)
                     zs[(size_t)tid * S + j] = z;
@@ -285,7 +285,7 @@ costas_kernel(const float2 *__restrict__ d, int nframes, int nsym, int dstride, 
     const LoopGains lg = {gains[2 * b], gains[2 * b + 1], min_freq, max_freq};
     const float2 *p = d + (size_t)f * dstride;
     for (int i = 0; i < nsym; i++) {
-        const float2 z = costas_step(st, lg, p[i]);
+        const float2 z = i == 0 ? costas_step<true>(st, lg, p[i]) : costas_step<false>(st, lg, p[i]);
         if (sym) sym[(size_t)t * nsym + i] = (uint8_t)slicer(z);
         if (costas) costas[(size_t)t * nsym + i] = z;
     }

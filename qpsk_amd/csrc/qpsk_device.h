@@ -63,10 +63,14 @@ __device__ __forceinline__ int slicer(float2 z)
     return ((ri < 0.0f) ? 2 : 0) | ((rr < 0.0f) ? 1 : 0);
 }
 
-/* one iteration of qpsk.c:196-212: returns the de-rotated symbol, advances the loop */
+/* one iteration of qpsk.c:196-212: returns the de-rotated symbol, advances the loop.
+ * EXACT_ZERO = true uses the sin/cos form that also reproduces sin(-0) = -0; the faster form is
+ * identical for every other argument and a -0 phase can only be LOADED, never produced by the loop
+ * (x + y is -0 only if both are), so callers run their first step with EXACT_ZERO = true. */
+template <bool EXACT_ZERO = false>
 __device__ __forceinline__ float2 costas_step(Loop &st, const LoopGains &g, float2 d)
 {
-    const SinCos w = sincos_f32(st.phase);
+    const SinCos w = EXACT_ZERO ? sincos_f32(st.phase) : sincos_f32_costas(st.phase);
     /* d * (cos - j sin)  (qpsk.c:197, qpsk.h:36) */
     float2 z;
     z.x = d.x * w.c + d.y * w.s;

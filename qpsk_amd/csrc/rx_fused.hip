@@ -1,0 +1,352 @@
+/*
+ * rx_fused.hip -- the hot kernel: decimating RRC FIR + Costas loop + slicer in
+ * one pass over the input (reference rrc_fir.c:17-30 evaluated only at the
+ * samples qpsk.c:190 keeps, then qpsk.c:196-212 / costas_loop.c:44-74).
+ *
+ * Shape of the problem on MI355X ("rx_fused_pipe"):
+ *   - the FIR is throughput work: 127 unfused mul+add pairs per symbol, any
+ *     number of symbols in parallel;
+ *   - the Costas loop is a strict recurrence per frame (phase -> sincos ->
+ *     rotate -> detector -> phase): one wave can issue one VALU instruction
+ *     per ~5 cycles, dependent ones every ~8, so a frame's 2048 symbols cost
+ *     2048 x (instructions per step) x 5 cycles however many CUs idle.
+ * So each workgroup is a producer/consumer pipeline in LDS:
+ *   wave 0           Costas + slicer, one lane per (frame, loop), never waits for HBM;
+ *   waves 1..NF      FIR: each owns 4 frames outright (loads, history, filter),
+ *                    so FIR waves never synchronise with each other, only with
+ *                    wave 0 through two monotonic counters in LDS.
+ *
+ * FIR wave layout: lane = (frame f of 4) x (q of 16); per chunk of S = 64
+ * symbols the lane produces the R = 4 consecutive symbols 4q..4q+3 of its
+ * frame with a sliding window: one 8-byte LDS read feeds up to 4 of the 508
+ * multiply-adds, the 127 taps live in VGPRs, each symbol's taps are summed
+ * 0..126 in one fp32 accumulator (bit-exactness).
+ * LDS image of a frame's window: position p (0 = the oldest sample the
+ * chunk needs, i.e. sample chunk_start + index - 126) at float2 slot
+ * p + p/32; lanes of one frame are 32 samples apart -> 33 slots -> the 16 x 2
+ * lanes of a half wave hit 32 distinct even banks.  The per-frame decimation
+ * index is absorbed when the window is WRITTEN (two per-lane base addresses),
+ * so every FIR read is "one VGPR base + immediate".
+ *
+ * HBM traffic: every input sample is read exactly once (16-byte coalesced
+ * loads, prefetched one chunk ahead into registers); 1 byte per symbol out.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "qpsk_device.h"
+#include "kernels.h"
+
+namespace qpsk {
+
+namespace pipe {
+
+constexpr int C = 8;             /* CYCLES this instantiation is built for */
+constexpr int R = 4;             /* symbols per FIR lane per chunk */
+constexpr int QL = 16;           /* lanes per frame */
+constexpr int FWV = 64 / QL;     /* frames per FIR wave */
+constexpr int S = R * QL;        /* symbols per chunk */
+constexpr int CH = S * C;        /* samples per chunk per frame */
+constexpr int TSTEPS = NTAPS + C * (R - 1);
+constexpr int WL = CH + 128;     /* window positions kept per frame */
+constexpr int WSLOTS = ((WL + WL / 32 + 1 + 31) / 32) * 32 + 16; /* padded, frame stride = 16 (mod 32) slots */
+constexpr int DR = 2;            /* depth of the symbol rings in chunks */
+constexpr int DSTRIDE = DR * S + 1;   /* odd: the Costas lanes of different frames hit different banks */
+constexpr int MAX_NF = 4;
+constexpr int SPIN_LIMIT = 1 << 24;
+
+struct Smem {
+    float taps[128];
+    int ready[MAX_NF];        /* chunks produced, per FIR wave */
+    int consumed;             /* chunks consumed by the Costas wave */
+    int abort_flag;
+    int pad_[2];
+};
+
+__device__ __forceinline__ int ld_acquire(const int *p)
+{
+    int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return v;
+}
+
+__device__ __forceinline__ void st_release(int *p, int v)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+/* bounded wait until *p >= target; false if the workgroup gave up */
+__device__ __forceinline__ bool wait_ge(int *p, int target, int *abort_flag)
+{
+    int spins = 0;
+    while (ld_acquire(p) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return false;
+        }
+    }
+    return true;
+}
+
+} // namespace pipe
+
+using namespace pipe;
+
+__global__ void __launch_bounds__(64 * (MAX_NF + 1))
+rx_fused_pipe_kernel(FusedArgs a, int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem *sm = reinterpret_cast<Smem *>(smem_raw);
+    const int NF = (int)blockDim.x / 64 - 1;
+    const int G = NF * FWV;
+    const int nbw = a.nbw;
+    float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));   /* [G][WSLOTS] */
+    float2 *dring = win + (size_t)G * WSLOTS;                              /* [G][DSTRIDE] */
+    float2 *zring = dring + (size_t)G * DSTRIDE;                           /* [G*nbw][DSTRIDE] (only if a.costas) */
+    uint8_t *sring = reinterpret_cast<uint8_t *>(zring + (a.costas ? (size_t)G * nbw * DSTRIDE : 0)); /* [G*nbw][DR*S] */
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int L = a.frame_size, N = a.nsym;
+    const int f0 = blockIdx.x * G;
+    const int nchunks = (N + S - 1) / S;
+
+    /* ---- common prologue: taps, counters, zeroed windows (= fresh delay lines, qpsk.c:37) */
+    for (int i = tid; i < 128; i += blockDim.x)
+        sm->taps[i] = i < NTAPS ? a.taps[i] : 0.0f;
+    if (tid < MAX_NF) sm->ready[tid] = 0;
+    if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
+    for (int i = tid; i < G * WSLOTS; i += blockDim.x)
+        win[i] = make_float2(0.0f, 0.0f);
+    __syncthreads();
+
+    if (wave == 0) {
+        /* =============================== Costas + slicer wave ===================================== */
+        __builtin_amdgcn_s_setprio(3);
+        const int g = lane / nbw, b = lane - g * nbw;
+        const bool active = lane < G * nbw && f0 + g < a.nframes;
+        Loop st = {0.0f, 0.0f};
+        LoopGains lg = {0.0f, 0.0f, a.min_freq, a.max_freq};
+        if (active) {
+            lg.alpha = a.gains[2 * b];
+            lg.beta = a.gains[2 * b + 1];
+            if (a.state_in) {
+                st.phase = a.state_in[2 * ((size_t)(f0 + g) * nbw + b)];
+                st.freq = a.state_in[2 * ((size_t)(f0 + g) * nbw + b) + 1];
+            }
+        }
+        const int gw = (lane < G * nbw ? g : 0) / FWV;       /* the FIR wave that feeds this lane */
+        const float2 *dl = dring + (size_t)(lane < G * nbw ? g : 0) * DSTRIDE;
+        float2 *zl = zring + (size_t)lane * DSTRIDE;
+        uint8_t *sl = sring + (size_t)lane * (DR * S);
+        bool ok = true;
+        for (int c = 0; c < nchunks && ok; c++) {
+            ok = wait_ge(&sm->ready[gw], c + 1, &sm->abort_flag);
+            if (!__all(ok)) { ok = false; break; }
+            const int slot = (c % DR) * S;
+            const int cnt = min(S, N - c * S);
+            if (active) {
+                int j = 0;
+                if (c == 0) { /* a loaded phase may be -0: first step with the form that is exact there too */
+                    const float2 z = costas_step<true>(st, lg, dl[slot]);
+                    sl[slot] = (uint8_t)slicer(z);
+                    if (a.costas) zl[slot] = z;
+                    j = 1;
+                }
+#pragma unroll 4
+                for (; j < cnt; j++) {
+                    const float2 z = costas_step<false>(st, lg, dl[slot + j]);
+                    sl[slot + j] = (uint8_t)slicer(z);
+                    if (a.costas) zl[slot + j] = z;
+                }
+            }
+            if (lane == 0) st_release(&sm->consumed, c + 1);
+        }
+        if (active && ok) {
+            const size_t o = (size_t)(f0 + g) * nbw + b;
+            if (a.freq) a.freq[o] = st.freq;
+            if (a.phase) a.phase[o] = st.phase;
+            if (a.hz) a.hz[o] = (float)((double)st.freq * a.rs / TAU); /* qpsk.c:217 */
+            if (a.state_out) { a.state_out[2 * o] = st.phase; a.state_out[2 * o + 1] = st.freq; }
+        }
+        if (!ok && lane == 0) atomicExch(status, 1);
+        return;
+    }
+
+    /* ======================================= FIR waves =========================================== */
+    const int w = wave - 1;                 /* FIR wave index */
+    const int fl = lane / QL, q = lane % QL;
+    const int g = w * FWV + fl;             /* frame slot in the workgroup */
+    const int frame = f0 + g;
+    const bool fvalid = frame < a.nframes;
+    int idx = a.index ? (fvalid ? a.index[frame] : 0) : a.fixed_index;   /* decimation offset, < C */
+
+    /* taps stay in LDS; the FIR loop keeps a rolling set of 4 groups of C taps in registers (broadcast reads) */
+    const float4 *taps4 = reinterpret_cast<const float4 *>(sm->taps);
+
+    float2 *wf = win + (size_t)g * WSLOTS;                 /* this frame's window */
+    const float2 *rd = wf + 33 * q;                        /* FIR read base: position 32q -> slot 33q */
+    /* write bases: loaded pair (s, s+1), s = 2*l16... one 16-byte load covers 128 samples of ONE frame, so the
+     * wave's 64 lanes sweep a frame in 4 loads; lane `lane` holds samples 2*lane, 2*lane+1 of each 128-block */
+    const float4 *src_frame[FWV];
+    int wr0[FWV], wr1[FWV];
+#pragma unroll
+    for (int ff = 0; ff < FWV; ff++) {
+        const int fr = f0 + w * FWV + ff;
+        const int ix = a.index ? (fr < a.nframes ? a.index[fr] : 0) : a.fixed_index;
+        const int p0 = 2 * lane + 126 - ix;               /* window position of sample 2*lane of the chunk */
+        wr0[ff] = (w * FWV + ff) * WSLOTS + p0 + (p0 >> 5);
+        wr1[ff] = (w * FWV + ff) * WSLOTS + (p0 + 1) + ((p0 + 1) >> 5);
+        src_frame[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(fr < a.nframes ? fr : 0) * L);
+    }
+    constexpr int NLD = CH / 128;                          /* 16-byte loads per frame per chunk */
+    float4 pre[FWV][NLD];
+
+    auto prefetch = [&](int c) {
+#pragma unroll
+        for (int ff = 0; ff < FWV; ff++) {
+            const bool fv = f0 + w * FWV + ff < a.nframes;
+#pragma unroll
+            for (int j = 0; j < NLD; j++) {
+                const int s = c * CH + 128 * j + 2 * lane;      /* first sample of the pair */
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (fv && s + 1 < L) {
+                    v = src_frame[ff][s >> 1];
+                } else if (fv && s < L) {                      /* odd tail (L odd): the pair straddles the end */
+                    const float2 t = a.x[(size_t)(f0 + w * FWV + ff) * L + s];
+                    v.x = t.x; v.y = t.y;
+                }
+                pre[ff][j] = v;
+            }
+        }
+    };
+
+    prefetch(0);
+    int flushed = 0;
+    bool ok = true;
+
+    auto flush_upto = [&](int upto) {
+        /* symbols (and costas_frame) of chunks [flushed, upto) of this wave's frames: staging -> global */
+        for (; flushed < upto; flushed++) {
+            const int slot = (flushed % DR) * S, sym0 = flushed * S;
+            const int cnt = min(S, N - sym0);
+            if (!fvalid) continue;
+            for (int b = 0; b < nbw; b++) {
+                const int row = g * nbw + b;
+                const size_t o = ((size_t)frame * nbw + b) * N + sym0 + R * q;
+                if (R * q + R <= cnt && ((N | sym0) & 3) == 0) {
+                    const uint32_t v = *reinterpret_cast<const uint32_t *>(sring + (size_t)row * (DR * S) + slot + R * q);
+                    *reinterpret_cast<uint32_t *>(a.sym + o) = v;
+                } else {
+                    for (int r = 0; r < R; r++)
+                        if (R * q + r < cnt) a.sym[o + r] = sring[(size_t)row * (DR * S) + slot + R * q + r];
+                }
+                if (a.costas) {
+                    for (int r = 0; r < R; r++)
+                        if (R * q + r < cnt) a.costas[o + r] = zring[(size_t)row * DSTRIDE + slot + R * q + r];
+                }
+            }
+        }
+    };
+
+    for (int c = 0; c < nchunks; c++) {
+        /* ring slot c % DR is free once chunk c - DR has been consumed; its outputs leave first */
+        if (c >= DR) {
+            ok = wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag);
+            if (!ok) break;
+            flush_upto(c - DR + 1);
+        }
+        /* history: positions [0, 126-idx) <- [CH, CH+126-idx) of the previous window (zeros for c = 0) */
+        {
+            float2 h[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                h[i] = wf[CH + CH / 32 + q + 16 * i + (i >> 1)];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                wf[q + 16 * i + (i >> 1)] = h[i];
+        }
+        /* new samples of this chunk (prefetched), then start the next chunk's loads */
+#pragma unroll
+        for (int ff = 0; ff < FWV; ff++) {
+#pragma unroll
+            for (int j = 0; j < NLD; j++) {
+                win[wr0[ff] + 132 * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
+                win[wr1[ff] + 132 * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
+            }
+        }
+        if (c + 1 < nchunks) prefetch(c + 1);
+
+        /* sliding-window FIR: symbol r of this lane uses tap k = t - C*r at window position 32q + t */
+        float2 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = make_float2(0.0f, 0.0f);
+        /* t = C*tb + u: symbol r needs tap group tb - r (taps C*(tb-r) .. +C-1), so each group of C taps is
+         * live for R consecutive blocks: group tb is fetched at block tb into slot tb % R */
+        static_assert(C == 8 && R == 4, "tap group rotation below is written for C = 8, R = 4");
+        float tg[R][C];
+#pragma unroll
+        for (int tb = 0; tb * C < TSTEPS; tb++) {
+            if (tb * C < NTAPS) {
+                const float4 ta = taps4[2 * tb], tb4 = taps4[2 * tb + 1];
+                tg[tb % R][0] = ta.x; tg[tb % R][1] = ta.y; tg[tb % R][2] = ta.z; tg[tb % R][3] = ta.w;
+                tg[tb % R][4] = tb4.x; tg[tb % R][5] = tb4.y; tg[tb % R][6] = tb4.z; tg[tb % R][7] = tb4.w;
+            }
+#pragma unroll
+            for (int u = 0; u < C; u++) {
+                const int t = tb * C + u;
+                if (t < TSTEPS) {
+                    const float2 v = rd[t + (t >> 5)];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int k = t - C * r;
+                        if (k >= 0 && k < NTAPS) fir_mac(acc[r], v, tg[(tb - r + R) % R][u]);
+                    }
+                }
+            }
+        }
+        /* decimated symbols -> ring; a pick at or past the end of the block is 0 (cannot happen for idx < C) */
+        float2 *dw = dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            dw[r] = fir_gain(acc[r]);
+        if (lane == 0) st_release(&sm->ready[w], c + 1);
+    }
+    if (ok) {
+        ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
+        if (ok) flush_upto(nchunks);
+    }
+    if (!ok && lane == 0) atomicExch(status, 1);
+    (void)idx;
+}
+
+size_t pipe_lds_bytes(int NF, int nbw, bool want_costas)
+{
+    const size_t G = (size_t)NF * FWV;
+    size_t b = sizeof(Smem) + sizeof(float2) * (G * WSLOTS + G * DSTRIDE);
+    if (want_costas) b += sizeof(float2) * G * nbw * DSTRIDE;
+    b += G * nbw * (DR * S);
+    return (b + 15) & ~(size_t)15;
+}
+
+int pipe_frames_per_wave(void) { return FWV; }
+int pipe_cycles(void) { return C; }
+int pipe_max_nf(void) { return MAX_NF; }
+
+int launch_rx_fused_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
+{
+    const int G = NF * FWV;
+    const int blocks = (a.nframes + G - 1) / G;
+    const size_t lds = pipe_lds_bytes(NF, a.nbw, a.costas != nullptr);
+    hipLaunchKernelGGL(rx_fused_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1)), lds, s, a, status);
+    hipError_t e = hipGetLastError();
+    return (int)e;
+}
+
+int prepare_pipe_kernel(void)
+{
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+}
+
+} // namespace qpsk

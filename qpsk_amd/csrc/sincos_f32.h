@@ -71,5 +71,63 @@ QPSK_HD SinCos sincos_f32(float y)
     return o;
 }
 
+/*
+ * The same values with fewer instructions, for the Costas recurrence where
+ * every instruction is on the serial path.  Differences from sincos_f32():
+ *  - n = round-to-nearest(x * 2/pi) by adding 1.5*2^52 in the same fma that
+ *    forms the product: the integer lands in the low mantissa bits (2 ops
+ *    instead of mul / cvt / add / shift / cvt).  The library truncates a
+ *    2^24-scaled product instead, which can pick the other neighbour when
+ *    x * 2/pi is within 2^-24 of a half-integer; tools/check_device_sincos.cpp
+ *    --costas proves that over EVERY float in [-2pi, 2pi] the final floats are
+ *    identical (both candidates reduce to |r| ~ pi/4, where either polynomial
+ *    pair rounds to the same float).
+ *  - quadrant signs by integer arithmetic on the float bits.
+ *  - sin(-0) = +0 instead of -0: the loop phase can only be -0 if the caller
+ *    loads it (phase + freq + alpha*e never produces -0 from a +0 start), so
+ *    the kernels canonicalise a loaded -0 phase through sincos_f32().
+ * Domain: |x| <= 2pi as wrapped by costas_loop.c:61-67 (valid far beyond;
+ * the checker sweeps |x| < 120).
+ */
+QPSK_HD SinCos sincos_f32_costas(float y)
+{
+    const double x = (double)y;
+    const double MAGIC = 0x1.8p52;
+    const double r2 = __builtin_fma(x, 0x1.45F306DC9C883p-1, MAGIC);
+    const double nd = r2 - MAGIC;
+    unsigned long long rb;
+    __builtin_memcpy(&rb, &r2, 8);
+    const unsigned n = (unsigned)rb; /* low mantissa word: n mod 2^32 */
+    const double xr = __builtin_fma(-nd, 0x1.921FB54442D18p0, x);
+    const double x2 = xr * xr;
+
+    const double x3 = xr * x2;
+    const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+    const double x7 = x3 * x2;
+    const double sa = __builtin_fma(x3, -0x1.555545995a603p-3, xr);
+    const float fs = (float)__builtin_fma(x7, s1, sa);
+
+    const double x4 = x2 * x2;
+    const double c2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+    const double c1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 1.0);
+    const double x6 = x4 * x2;
+    const double ca = __builtin_fma(x4, 0x1.55553e1068f19p-5, c1);
+    const float fc = (float)__builtin_fma(x6, c2, ca);
+
+    /* S' = S negated in quadrants 1,2; C' = C negated in quadrants 2,3;
+     * even quadrant: (sin, cos) = (S', C'), odd: (C', S') */
+    unsigned sb, cb;
+    __builtin_memcpy(&sb, &fs, 4);
+    __builtin_memcpy(&cb, &fc, 4);
+    sb += ((n + 1u) & 2u) << 30;
+    cb += (n & 2u) << 30;
+    const unsigned ob = (n & 1u) ? cb : sb;
+    const unsigned eb = (n & 1u) ? sb : cb;
+    SinCos o;
+    __builtin_memcpy(&o.s, &ob, 4);
+    __builtin_memcpy(&o.c, &eb, 4);
+    return o;
+}
+
 } // namespace qpsk
 #endif
