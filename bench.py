@@ -96,6 +96,7 @@ def note(msg):
 
 
 def main():
+    global L
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -103,7 +104,9 @@ def main():
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step (config 2: 4096)")
     ap.add_argument("--cpu-frames", type=int, default=512, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--frame-size", type=int, default=L, help="complex samples per frame (config 2: 16384)")
     args = ap.parse_args()
+    L = args.frame_size
 
     import torch
     import qpsk_amd

@@ -341,6 +341,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
     pick_tiling(c, nframes, nbw, &a.G, &a.S);
     a.index = idx;
     a.fixed_index = c->prm.fixed_index;
+    a.dbg = env_int("QPSK_PIPE_DBG", 0);
     a.taps = c->d_taps;
     a.gains = c->d_gains;
     a.nbw = nbw;

@@ -19,6 +19,7 @@ struct FusedArgs {
     int G, S;               /* frames per workgroup, symbols per chunk */
     const int32_t *index;   /* [nframes] or NULL -> fixed_index */
     int fixed_index;
+    int dbg;                /* measurement only: 1 = skip FIR arithmetic, 2 = skip the Costas recurrence */
     const float *taps;      /* [127] */
     const float *gains;     /* [nbw][2] alpha, beta */
     int nbw;

@@ -88,5 +88,34 @@ __device__ __forceinline__ float2 costas_step(Loop &st, const LoopGains &g, floa
     return z;
 }
 
+/*
+ * The same step written for the serial wave of rx_fused_pipe_kernel, where every instruction is on the
+ * critical path: no divergent branches (the detector and the clamp are selects, the phase wrap is taken
+ * only when some lane of the wave needs it), sin/cos in the Costas form.  FAST_CLAMP (host-checked:
+ * min_freq < 0 < max_freq) replaces the two compare/select pairs of costas_loop.c:69-74 by one median-of-3,
+ * which returns the same float for every non-NaN frequency when neither bound is a zero.
+ */
+template <bool FAST_CLAMP>
+__device__ __forceinline__ float2 costas_step_lean(float &phase, float &freq, float alpha, float beta,
+                                                   float min_freq, float max_freq, float2 d)
+{
+    const SinCos w = sincos_f32_costas(phase);
+    float2 z;
+    z.x = d.x * w.c + d.y * w.s;
+    z.y = d.y * w.c - d.x * w.s;
+    const float e = (z.x > 0.0f ? z.y : -z.y) - (z.y > 0.0f ? z.x : -z.x);
+    float f = freq + beta * e;
+    float p = phase + f + alpha * e;
+    if (__builtin_expect(__any(fabsf(p) >= TAU_F), 0))
+        p = phase_wrap(p);
+    if (FAST_CLAMP)
+        f = __builtin_amdgcn_fmed3f(f, min_freq, max_freq);
+    else
+        f = f > max_freq ? max_freq : (f < min_freq ? min_freq : f);
+    phase = p;
+    freq = f;
+    return z;
+}
+
 } // namespace qpsk
 #endif

@@ -103,8 +103,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     const int nbw = a.nbw;
     float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));   /* [G][WSLOTS] */
     float2 *dring = win + (size_t)G * WSLOTS;                              /* [G][DSTRIDE] */
-    float2 *zring = dring + (size_t)G * DSTRIDE;                           /* [G*nbw][DSTRIDE] (only if a.costas) */
-    uint8_t *sring = reinterpret_cast<uint8_t *>(zring + (a.costas ? (size_t)G * nbw * DSTRIDE : 0)); /* [G*nbw][DR*S] */
+    float2 *zring = dring + (size_t)G * DSTRIDE;                           /* [G*nbw][DSTRIDE] de-rotated symbols */
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = a.frame_size, N = a.nsym;
@@ -138,30 +137,38 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         const int gw = (lane < G * nbw ? g : 0) / FWV;       /* the FIR wave that feeds this lane */
         const float2 *dl = dring + (size_t)(lane < G * nbw ? g : 0) * DSTRIDE;
         float2 *zl = zring + (size_t)lane * DSTRIDE;
-        uint8_t *sl = sring + (size_t)lane * (DR * S);
+        /* one median-of-3 instead of two compare/select pairs when the clamp is the usual min < 0 < max */
+        const bool fast_clamp = a.min_freq < 0.0f && a.max_freq > 0.0f;
+        float ph = st.phase, fr = st.freq;
+        const float al = lg.alpha, be = lg.beta, fmin_ = a.min_freq, fmax_ = a.max_freq;
         bool ok = true;
         for (int c = 0; c < nchunks && ok; c++) {
             ok = wait_ge(&sm->ready[gw], c + 1, &sm->abort_flag);
             if (!__all(ok)) { ok = false; break; }
             const int slot = (c % DR) * S;
             const int cnt = min(S, N - c * S);
-            if (active) {
+            if (active && !(a.dbg & 2)) { /* ablation knob (QPSK_PIPE_DBG bit 1): skip the recurrence */
                 int j = 0;
                 if (c == 0) { /* a loaded phase may be -0: first step with the form that is exact there too */
-                    const float2 z = costas_step<true>(st, lg, dl[slot]);
-                    sl[slot] = (uint8_t)slicer(z);
-                    if (a.costas) zl[slot] = z;
+                    Loop s0 = {ph, fr};
+                    zl[slot] = costas_step<true>(s0, lg, dl[slot]);
+                    ph = s0.phase; fr = s0.freq;
                     j = 1;
                 }
+                /* the wave only de-rotates and advances the loop; the slicer runs in the FIR waves' flush */
+                if (fast_clamp) {
 #pragma unroll 4
-                for (; j < cnt; j++) {
-                    const float2 z = costas_step<false>(st, lg, dl[slot + j]);
-                    sl[slot + j] = (uint8_t)slicer(z);
-                    if (a.costas) zl[slot + j] = z;
+                    for (; j < cnt; j++)
+                        zl[slot + j] = costas_step_lean<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j]);
+                } else {
+#pragma unroll 4
+                    for (; j < cnt; j++)
+                        zl[slot + j] = costas_step_lean<false>(ph, fr, al, be, fmin_, fmax_, dl[slot + j]);
                 }
             }
             if (lane == 0) st_release(&sm->consumed, c + 1);
         }
+        st.phase = ph; st.freq = fr;
         if (active && ok) {
             const size_t o = (size_t)(f0 + g) * nbw + b;
             if (a.freq) a.freq[o] = st.freq;
@@ -202,21 +209,30 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     constexpr int NLD = CH / 128;                          /* 16-byte loads per frame per chunk */
     float4 pre[FWV][NLD];
 
+    /* L is even on this path (checked by the host), so a 16-byte pair is either inside the frame or past it.
+     * Loads are UNCONDITIONAL (a per-load branch would make the compiler wait for each load in turn): a
+     * chunk that lies inside every frame of the wave -- all but the last one -- loads straight; the tail
+     * chunk clamps the address into the frame and zeroes what lies past the end afterwards. */
+    const bool wave_frames_valid = f0 + w * FWV + FWV <= a.nframes;
     auto prefetch = [&](int c) {
+        if (wave_frames_valid && (c + 1) * CH <= L) {
 #pragma unroll
-        for (int ff = 0; ff < FWV; ff++) {
-            const bool fv = f0 + w * FWV + ff < a.nframes;
+            for (int ff = 0; ff < FWV; ff++)
 #pragma unroll
-            for (int j = 0; j < NLD; j++) {
-                const int s = c * CH + 128 * j + 2 * lane;      /* first sample of the pair */
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (fv && s + 1 < L) {
-                    v = src_frame[ff][s >> 1];
-                } else if (fv && s < L) {                      /* odd tail (L odd): the pair straddles the end */
-                    const float2 t = a.x[(size_t)(f0 + w * FWV + ff) * L + s];
-                    v.x = t.x; v.y = t.y;
+                for (int j = 0; j < NLD; j++)
+                    pre[ff][j] = src_frame[ff][(c * CH + 128 * j + 2 * lane) >> 1];
+        } else {
+#pragma unroll
+            for (int ff = 0; ff < FWV; ff++) {
+                const bool fv = f0 + w * FWV + ff < a.nframes;
+#pragma unroll
+                for (int j = 0; j < NLD; j++) {
+                    const int s = c * CH + 128 * j + 2 * lane;      /* first sample of the pair */
+                    const bool in = fv && s + 1 < L;
+                    float4 v = src_frame[ff][in ? (s >> 1) : 0];
+                    if (!in) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    pre[ff][j] = v;
                 }
-                pre[ff][j] = v;
             }
         }
     };
@@ -234,16 +250,22 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
             for (int b = 0; b < nbw; b++) {
                 const int row = g * nbw + b;
                 const size_t o = ((size_t)frame * nbw + b) * N + sym0 + R * q;
+                float2 z[R];
+                uint32_t packed = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    z[r] = zring[(size_t)row * DSTRIDE + slot + R * q + r];
+                    packed |= (uint32_t)slicer(z[r]) << (8 * r);   /* qpsk_demod(), qpsk.c:74-79 */
+                }
                 if (R * q + R <= cnt && ((N | sym0) & 3) == 0) {
-                    const uint32_t v = *reinterpret_cast<const uint32_t *>(sring + (size_t)row * (DR * S) + slot + R * q);
-                    *reinterpret_cast<uint32_t *>(a.sym + o) = v;
+                    *reinterpret_cast<uint32_t *>(a.sym + o) = packed;
                 } else {
                     for (int r = 0; r < R; r++)
-                        if (R * q + r < cnt) a.sym[o + r] = sring[(size_t)row * (DR * S) + slot + R * q + r];
+                        if (R * q + r < cnt) a.sym[o + r] = (uint8_t)(packed >> (8 * r));
                 }
                 if (a.costas) {
                     for (int r = 0; r < R; r++)
-                        if (R * q + r < cnt) a.costas[o + r] = zring[(size_t)row * DSTRIDE + slot + R * q + r];
+                        if (R * q + r < cnt) a.costas[o + r] = z[r];
                 }
             }
         }
@@ -285,6 +307,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
          * live for R consecutive blocks: group tb is fetched at block tb into slot tb % R */
         static_assert(C == 8 && R == 4, "tap group rotation below is written for C = 8, R = 4");
         float tg[R][C];
+        if (!(a.dbg & 1)) /* ablation knob (QPSK_PIPE_DBG bit 0): skip the filter arithmetic, keep the traffic */
 #pragma unroll
         for (int tb = 0; tb * C < TSTEPS; tb++) {
             if (tb * C < NTAPS) {
@@ -323,9 +346,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
 size_t pipe_lds_bytes(int NF, int nbw, bool want_costas)
 {
     const size_t G = (size_t)NF * FWV;
-    size_t b = sizeof(Smem) + sizeof(float2) * (G * WSLOTS + G * DSTRIDE);
-    if (want_costas) b += sizeof(float2) * G * nbw * DSTRIDE;
-    b += G * nbw * (DR * S);
+    (void)want_costas;
+    size_t b = sizeof(Smem) + sizeof(float2) * (G * WSLOTS + G * DSTRIDE + G * nbw * DSTRIDE);
     return (b + 15) & ~(size_t)15;
 }
 

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Measurement helper (GPU box): time qpsk_rx_batch on the bench workload under several tuning /
+ablation environment settings in ONE process (the library reads QPSK_* with getenv at every call).
+
+    python tools/sweep.py [--frames 4096] "QPSK_PIPE_DBG=1" "QPSK_PIPE_NF=2 QPSK_PIPE_DBG=3" ...
+An empty string is the default configuration.  Interleaved rounds, median of per-launch HIP-event times.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=4096)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--per-round", type=int, default=4)
+    ap.add_argument("configs", nargs="*", default=[""])
+    args = ap.parse_args()
+    import torch
+    import qpsk_amd
+    dev = torch.device("cuda", 0)
+    F = args.frames
+    m = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=qpsk_amd.TIMING_FIXED,
+                       fixed_index=bench.FIXED_INDEX)
+    x = bench.synth_frames_gpu(torch, dev, F, m.taps, seed=1000)
+    sym = torch.empty((F, m.nsym), dtype=torch.uint8, device=dev)
+    freq = torch.empty((F,), dtype=torch.float32, device=dev)
+    phase = torch.empty((F,), dtype=torch.float32, device=dev)
+    times = {c: [] for c in args.configs}
+    keys = set()
+    for c in args.configs:
+        for kv in c.split():
+            keys.add(kv.split("=")[0])
+    for r in range(args.rounds + 1):
+        for c in args.configs:
+            for k in keys:
+                os.environ.pop(k, None)
+            for kv in c.split():
+                k, v = kv.split("=")
+                os.environ[k] = v
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.per_round)]
+            for a, b in evs:
+                a.record()
+                m.rx_batch_raw(x, F, sym, freq, phase)
+                b.record()
+            torch.cuda.synchronize()
+            if r > 0:
+                times[c] += [a.elapsed_time(b) for a, b in evs]
+    nbytes = 8.0 * F * bench.L
+    for c in args.configs:
+        t = np.array(times[c])
+        print("%-40s median %.4f ms  min %.4f ms  -> %.0f GB/s (%.1f%% of 8 TB/s)" % (
+            c or "(default)", np.median(t), t.min(), nbytes / np.median(t) / 1e6, nbytes / np.median(t) / 1e6 / 80.0))
+
+
+if __name__ == "__main__":
+    main()
