@@ -117,5 +117,70 @@ __device__ __forceinline__ float2 costas_step_lean(float &phase, float &freq, fl
     return z;
 }
 
+/*
+ * The shortest form of the step, for the serial wave of rx_fused_pipe_kernel.  Three exact rewrites:
+ *
+ * 1. sin/cos polynomials in Horner form (8 fp64 ops instead of 11).  Rounding differs inside the double
+ *    evaluation, yet tools/check_device_sincos.cpp --horner shows the FLOAT results equal libm's for every
+ *    float in [-2pi, 2pi] (2,173,837,239 arguments, 0 mismatches).
+ * 2. The quadrant of the phase is NOT applied on the serial path.  With S, C the raw polynomial values
+ *    (sine/cosine of the reduced argument) and q the quadrant, the de-rotated symbol of qpsk.c:197 is
+ *        z = T * (-j)^q,   T = d * (C - jS)
+ *    bit for bit (negation and swapping commute with every rounding involved), and the QPSK detector
+ *    sgn(I)Q - sgn(Q)I (costas_loop.c:44-47) takes the same value on T as on z -- it is invariant under
+ *    quarter turns -- except when a component of T is exactly zero, where the reference's sgn(0) = -1
+ *    breaks the symmetry.  So the wave computes T and e(T); if any lane has T.x*T.y == 0 (exact zero, or
+ *    an underflowing product: a superset) the wave redoes that step through z.  The consumer of the
+ *    (T, q) record -- the FIR waves' flush -- forms z for the slicer and for costas_frame[].
+ * 3. FAST_CLAMP as in costas_step_lean().
+ *
+ * Returns T in (tx, ty) and the quadrant bits in q (low two bits significant).
+ */
+/* z = T * (-j)^q:  q = 0: (T.x, T.y)   1: (T.y, -T.x)   2: (-T.x, -T.y)   3: (-T.y, T.x) */
+__device__ __forceinline__ float2 apply_quadrant(float tx, float ty, unsigned q)
+{
+    const float a = (q & 1u) ? ty : tx;
+    const float b = (q & 1u) ? tx : ty;
+    float2 z;
+    z.x = (q & 2u) ? -a : a;
+    z.y = ((q + 1u) & 2u) ? -b : b;
+    return z;
+}
+
+__device__ __forceinline__ float detector(float zx, float zy)
+{
+    return (zx > 0.0f ? zy : -zy) - (zy > 0.0f ? zx : -zx);
+}
+
+template <bool FAST_CLAMP>
+__device__ __forceinline__ void costas_step_t(float &phase, float &freq, float alpha, float beta, float min_freq,
+                                              float max_freq, float2 d, float &tx, float &ty, unsigned &q)
+{
+    const SinCosRaw w = sincos_raw_horner(phase);
+    tx = d.x * w.c + d.y * w.s;
+    ty = d.y * w.c - d.x * w.s;
+    q = w.n;
+    float e = detector(tx, ty);
+    float f = freq + beta * e;
+    float p = phase + f + alpha * e;
+    const bool zero = tx * ty == 0.0f;
+    const bool wrap = fabsf(p) >= TAU_F;
+    if (__builtin_expect(__any(zero || wrap), 0)) {
+        if (zero) { /* sgn(0) = -1 is not rotation invariant: take the detector on z itself */
+            const float2 z = apply_quadrant(tx, ty, q);
+            e = detector(z.x, z.y);
+            f = freq + beta * e;
+            p = phase + f + alpha * e;
+        }
+        p = phase_wrap(p);
+    }
+    if (FAST_CLAMP)
+        f = __builtin_amdgcn_fmed3f(f, min_freq, max_freq);
+    else
+        f = f > max_freq ? max_freq : (f < min_freq ? min_freq : f);
+    phase = p;
+    freq = f;
+}
+
 } // namespace qpsk
 #endif

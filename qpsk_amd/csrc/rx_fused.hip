@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "qpsk_device.h"
+#include "costas_asm.h"
 #include "kernels.h"
 
 namespace qpsk {
@@ -93,17 +94,19 @@ __device__ __forceinline__ bool wait_ge(int *p, int target, int *abort_flag)
 
 using namespace pipe;
 
-__global__ void __launch_bounds__(64 * (MAX_NF + 1))
+__global__ void __launch_bounds__(64 * (MAX_NF + 2))
 rx_fused_pipe_kernel(FusedArgs a, int *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem *sm = reinterpret_cast<Smem *>(smem_raw);
-    const int NF = (int)blockDim.x / 64 - 1;
+    const int spare = (a.dbg & 4) ? 1 : 0;   /* experiment: one idle wave so that the Costas wave has a SIMD to itself */
+    const int NF = (int)blockDim.x / 64 - 1 - spare;
     const int G = NF * FWV;
     const int nbw = a.nbw;
     float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));   /* [G][WSLOTS] */
     float2 *dring = win + (size_t)G * WSLOTS;                              /* [G][DSTRIDE] */
-    float2 *zring = dring + (size_t)G * DSTRIDE;                           /* [G*nbw][DSTRIDE] de-rotated symbols */
+    float2 *zring = dring + (size_t)G * DSTRIDE;                           /* [G*nbw][DSTRIDE] T = d*(C - jS), see costas_step_t */
+    uint8_t *qring = reinterpret_cast<uint8_t *>(zring + (size_t)G * nbw * DSTRIDE); /* [G*nbw][DR*S] quadrant of each symbol */
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = a.frame_size, N = a.nsym;
@@ -137,6 +140,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         const int gw = (lane < G * nbw ? g : 0) / FWV;       /* the FIR wave that feeds this lane */
         const float2 *dl = dring + (size_t)(lane < G * nbw ? g : 0) * DSTRIDE;
         float2 *zl = zring + (size_t)lane * DSTRIDE;
+        uint8_t *ql = qring + (size_t)lane * (DR * S);
         /* one median-of-3 instead of two compare/select pairs when the clamp is the usual min < 0 < max */
         const bool fast_clamp = a.min_freq < 0.0f && a.max_freq > 0.0f;
         float ph = st.phase, fr = st.freq;
@@ -152,18 +156,55 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                 if (c == 0) { /* a loaded phase may be -0: first step with the form that is exact there too */
                     Loop s0 = {ph, fr};
                     zl[slot] = costas_step<true>(s0, lg, dl[slot]);
+                    ql[slot] = 0;   /* already de-rotated: quadrant 0 */
                     ph = s0.phase; fr = s0.freq;
                     j = 1;
                 }
-                /* the wave only de-rotates and advances the loop; the slicer runs in the FIR waves' flush */
+                /* the wave only advances the loop and leaves (T, quadrant); de-rotation to z, the slicer and
+                 * costas_frame[] happen in the FIR waves' flush */
+                /* the next symbol is fetched from LDS one whole step ahead, so the recurrence never waits for
+                 * the LDS pipe (which the FIR waves keep busy); reading one slot past the chunk is harmless
+                 * (next slot or the row's padding element) */
+                if (fast_clamp && !(a.dbg & 8)) {
+                    /* groups of 8 steps in the hand-scheduled stream (costas_asm.h); a group it abandons
+                     * (exact-zero detector input, double wrap) is redone here with the C++ step */
+                    while (cnt - j >= 8) {
+                        unsigned da = lds_addr(dl + slot + j), za = lds_addr(zl + slot + j), qa = lds_addr(ql + slot + j);
+                        unsigned long long fl;
+                        const unsigned want = (unsigned)(cnt - j) / 8;
+                        const unsigned left = costas_asm_run(ph, fr, da, za, qa, want, al, be, fmin_, fmax_, fl);
+                        j += 8 * (int)(want - left);
+                        if (left != 0) {
+                            for (int i = 0; i < 8; i++, j++) {
+                                float tx, ty; unsigned qq;
+                                costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
+                                zl[slot + j] = make_float2(tx, ty);
+                                ql[slot + j] = (uint8_t)qq;
+                            }
+                        }
+                    }
+                }
+                float2 dcur = dl[slot + j];
                 if (fast_clamp) {
-#pragma unroll 4
-                    for (; j < cnt; j++)
-                        zl[slot + j] = costas_step_lean<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j]);
+#pragma unroll 1
+                    for (; j < cnt; j++) {
+                        const float2 dnext = dl[slot + j + 1];
+                        float tx, ty; unsigned qq;
+                        costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
+                        zl[slot + j] = make_float2(tx, ty);
+                        ql[slot + j] = (uint8_t)qq;
+                        dcur = dnext;
+                    }
                 } else {
 #pragma unroll 4
-                    for (; j < cnt; j++)
-                        zl[slot + j] = costas_step_lean<false>(ph, fr, al, be, fmin_, fmax_, dl[slot + j]);
+                    for (; j < cnt; j++) {
+                        const float2 dnext = dl[slot + j + 1];
+                        float tx, ty; unsigned qq;
+                        costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
+                        zl[slot + j] = make_float2(tx, ty);
+                        ql[slot + j] = (uint8_t)qq;
+                        dcur = dnext;
+                    }
                 }
             }
             if (lane == 0) st_release(&sm->consumed, c + 1);
@@ -181,7 +222,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     }
 
     /* ======================================= FIR waves =========================================== */
-    const int w = wave - 1;                 /* FIR wave index */
+    if (spare && wave == 4) return;          /* shares SIMD 0 with wave 0 under the 0,2,1,3 round-robin placement */
+    const int w = (spare && wave > 4) ? wave - 2 : wave - 1;   /* FIR wave index */
     const int fl = lane / QL, q = lane % QL;
     const int g = w * FWV + fl;             /* frame slot in the workgroup */
     const int frame = f0 + g;
@@ -254,7 +296,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                 uint32_t packed = 0;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    z[r] = zring[(size_t)row * DSTRIDE + slot + R * q + r];
+                    const float2 tq = zring[(size_t)row * DSTRIDE + slot + R * q + r];
+                    z[r] = apply_quadrant(tq.x, tq.y, qring[(size_t)row * (DR * S) + slot + R * q + r]);   /* qpsk.c:197 */
                     packed |= (uint32_t)slicer(z[r]) << (8 * r);   /* qpsk_demod(), qpsk.c:74-79 */
                 }
                 if (R * q + R <= cnt && ((N | sym0) & 3) == 0) {
@@ -347,7 +390,7 @@ size_t pipe_lds_bytes(int NF, int nbw, bool want_costas)
 {
     const size_t G = (size_t)NF * FWV;
     (void)want_costas;
-    size_t b = sizeof(Smem) + sizeof(float2) * (G * WSLOTS + G * DSTRIDE + G * nbw * DSTRIDE);
+    size_t b = sizeof(Smem) + sizeof(float2) * (G * WSLOTS + G * DSTRIDE + G * nbw * DSTRIDE) + G * nbw * (DR * S);
     return (b + 15) & ~(size_t)15;
 }
 
@@ -360,7 +403,7 @@ int launch_rx_fused_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
     const int G = NF * FWV;
     const int blocks = (a.nframes + G - 1) / G;
     const size_t lds = pipe_lds_bytes(NF, a.nbw, a.costas != nullptr);
-    hipLaunchKernelGGL(rx_fused_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1)), lds, s, a, status);
+    hipLaunchKernelGGL(rx_fused_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1 + ((a.dbg & 4) ? 1 : 0))), lds, s, a, status);
     hipError_t e = hipGetLastError();
     return (int)e;
 }

@@ -129,5 +129,52 @@ QPSK_HD SinCos sincos_f32_costas(float y)
     return o;
 }
 
+/*
+ * Raw form for the serial wave of rx_fused_pipe_kernel: the two polynomial values on the reduced
+ * argument (Horner evaluation, 8 fp64 operations after x^2) and the quadrant number, WITHOUT the
+ * quadrant fix-up (the kernel applies it off the serial path, see costas_step_t in qpsk_device.h).
+ * sincos_from_raw() is that fix-up; tools/check_device_sincos.cpp --horner checks the pair against
+ * libm over every float in [-2pi, 2pi] (0 mismatches; the Horner rounding differs from the library's
+ * evaluation order inside the double polynomial but never in the float result on that domain).
+ */
+struct SinCosRaw {
+    float s, c;   /* sine / cosine polynomial on the reduced argument */
+    unsigned n;   /* round(x * 2/pi) mod 2^32; quadrant = n & 3 */
+};
+
+QPSK_HD SinCosRaw sincos_raw_horner(float y)
+{
+    const double x = (double)y;
+    const double MAGIC = 0x1.8p52;
+    const double r2 = __builtin_fma(x, 0x1.45F306DC9C883p-1, MAGIC);
+    const double nd = r2 - MAGIC;
+    unsigned long long rb;
+    __builtin_memcpy(&rb, &r2, 8);
+    const double xr = __builtin_fma(-nd, 0x1.921FB54442D18p0, x);
+    const double x2 = xr * xr;
+    const double x3 = xr * x2;
+    double u = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+    double t = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+    u = __builtin_fma(x2, u, -0x1.555545995a603p-3);
+    t = __builtin_fma(x2, t, 0x1.55553e1068f19p-5);
+    SinCosRaw o;
+    o.s = (float)__builtin_fma(x3, u, xr);
+    t = __builtin_fma(x2, t, -0x1.ffffffd0c621cp-2);
+    o.c = (float)__builtin_fma(x2, t, 1.0);
+    o.n = (unsigned)rb;
+    return o;
+}
+
+QPSK_HD SinCos sincos_from_raw(SinCosRaw r)
+{
+    /* quadrant 0: (S, C)  1: (C, -S)  2: (-S, -C)  3: (-C, S) */
+    const float a = (r.n & 1u) ? r.c : r.s;
+    const float b = (r.n & 1u) ? r.s : r.c;
+    SinCos o;
+    o.s = (r.n & 2u) ? -a : a;
+    o.c = ((r.n + 1u) & 2u) ? -b : b;
+    return o;
+}
+
 } // namespace qpsk
 #endif
