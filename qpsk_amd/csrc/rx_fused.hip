@@ -51,7 +51,9 @@ constexpr int TSTEPS = NTAPS + C * (R - 1);
 constexpr int WL = CH + 128;     /* window positions kept per frame */
 constexpr int WSLOTS = ((WL + WL / 32 + 1 + 31) / 32) * 32 + 16; /* padded, frame stride = 16 (mod 32) slots */
 constexpr int DR = 2;            /* depth of the symbol rings in chunks */
-constexpr int DSTRIDE = DR * S + 1;   /* odd: the Costas lanes of different frames hit different banks */
+constexpr int DSTRIDE = DR * S + 2;   /* float2 slots per frame row: 16-byte aligned rows (the Costas wave reads two symbols
+                                         per ds_read_b128), 4 dwords (mod 64) apart so 16 lanes hit 16 different bank quads */
+constexpr int ZSTRIDE = DR * S + 1;   /* 16-byte records (T.x, T.y, n, -) per Costas row */
 constexpr int MAX_NF = 4;
 constexpr int SPIN_LIMIT = 1 << 24;
 
@@ -99,14 +101,17 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem *sm = reinterpret_cast<Smem *>(smem_raw);
-    const int spare = (a.dbg & 4) ? 1 : 0;   /* experiment: one idle wave so that the Costas wave has a SIMD to itself */
+    /* With 4 FIR waves the workgroup would be 5 waves on 4 SIMDs and the serial wave would share its SIMD
+     * (waves are dealt round-robin, so wave 4 lands beside wave 0).  The host then launches a sixth wave and
+     * wave 4 retires at once: measured -6 % kernel time (sweep QPSK_PIPE_NOSPARE=1). */
+    const int spare = (a.dbg & 4) ? 0 : ((int)blockDim.x / 64 == MAX_NF + 2 ? 1 : 0);
     const int NF = (int)blockDim.x / 64 - 1 - spare;
     const int G = NF * FWV;
     const int nbw = a.nbw;
     float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));   /* [G][WSLOTS] */
     float2 *dring = win + (size_t)G * WSLOTS;                              /* [G][DSTRIDE] */
-    float2 *zring = dring + (size_t)G * DSTRIDE;                           /* [G*nbw][DSTRIDE] T = d*(C - jS), see costas_step_t */
-    uint8_t *qring = reinterpret_cast<uint8_t *>(zring + (size_t)G * nbw * DSTRIDE); /* [G*nbw][DR*S] quadrant of each symbol */
+    float4 *zring = reinterpret_cast<float4 *>(dring + (size_t)G * DSTRIDE); /* [G*nbw][ZSTRIDE] records (T.x, T.y, n, -):
+                                                                               T = d*(C - jS), quadrant = n & 3, see costas_step_t */
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int L = a.frame_size, N = a.nsym;
@@ -139,8 +144,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         }
         const int gw = (lane < G * nbw ? g : 0) / FWV;       /* the FIR wave that feeds this lane */
         const float2 *dl = dring + (size_t)(lane < G * nbw ? g : 0) * DSTRIDE;
-        float2 *zl = zring + (size_t)lane * DSTRIDE;
-        uint8_t *ql = qring + (size_t)lane * (DR * S);
+        float4 *zl = zring + (size_t)lane * ZSTRIDE;
         /* one median-of-3 instead of two compare/select pairs when the clamp is the usual min < 0 < max */
         const bool fast_clamp = a.min_freq < 0.0f && a.max_freq > 0.0f;
         float ph = st.phase, fr = st.freq;
@@ -155,10 +159,17 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                 int j = 0;
                 if (c == 0) { /* a loaded phase may be -0: first step with the form that is exact there too */
                     Loop s0 = {ph, fr};
-                    zl[slot] = costas_step<true>(s0, lg, dl[slot]);
-                    ql[slot] = 0;   /* already de-rotated: quadrant 0 */
+                    const float2 z0 = costas_step<true>(s0, lg, dl[slot]);
+                    zl[slot] = make_float4(z0.x, z0.y, 0.0f, 0.0f);   /* already de-rotated: quadrant 0 */
                     ph = s0.phase; fr = s0.freq;
                     j = 1;
+                    if (cnt > 1) {   /* the stream below starts on an even symbol (16-byte aligned pair reads) */
+                        float tx, ty; unsigned qq;
+                        if (fast_clamp) costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + 1], tx, ty, qq);
+                        else costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dl[slot + 1], tx, ty, qq);
+                        zl[slot + 1] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
+                        j = 2;
+                    }
                 }
                 /* the wave only advances the loop and leaves (T, quadrant); de-rotation to z, the slicer and
                  * costas_frame[] happen in the FIR waves' flush */
@@ -169,17 +180,16 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                     /* groups of 8 steps in the hand-scheduled stream (costas_asm.h); a group it abandons
                      * (exact-zero detector input, double wrap) is redone here with the C++ step */
                     while (cnt - j >= 8) {
-                        unsigned da = lds_addr(dl + slot + j), za = lds_addr(zl + slot + j), qa = lds_addr(ql + slot + j);
+                        unsigned da = lds_addr(dl + slot + j), za = lds_addr(zl + slot + j);
                         unsigned long long fl;
-                        const unsigned want = (unsigned)(cnt - j) / 8;
-                        const unsigned left = costas_asm_run(ph, fr, da, za, qa, want, al, be, fmin_, fmax_, fl);
+                        const unsigned want = __builtin_amdgcn_readfirstlane((unsigned)(cnt - j) / 8);   /* wave-uniform */
+                        const unsigned left = costas_asm_run(ph, fr, da, za, want, al, be, fmin_, fmax_, fl);
                         j += 8 * (int)(want - left);
                         if (left != 0) {
                             for (int i = 0; i < 8; i++, j++) {
                                 float tx, ty; unsigned qq;
                                 costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
-                                zl[slot + j] = make_float2(tx, ty);
-                                ql[slot + j] = (uint8_t)qq;
+                                zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
                             }
                         }
                     }
@@ -191,8 +201,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                         const float2 dnext = dl[slot + j + 1];
                         float tx, ty; unsigned qq;
                         costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
-                        zl[slot + j] = make_float2(tx, ty);
-                        ql[slot + j] = (uint8_t)qq;
+                        zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
                         dcur = dnext;
                     }
                 } else {
@@ -201,8 +210,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                         const float2 dnext = dl[slot + j + 1];
                         float tx, ty; unsigned qq;
                         costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
-                        zl[slot + j] = make_float2(tx, ty);
-                        ql[slot + j] = (uint8_t)qq;
+                        zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
                         dcur = dnext;
                     }
                 }
@@ -222,7 +230,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     }
 
     /* ======================================= FIR waves =========================================== */
-    if (spare && wave == 4) return;          /* shares SIMD 0 with wave 0 under the 0,2,1,3 round-robin placement */
+    if (spare && wave == 4) return;          /* the wave that would share a SIMD with wave 0 */
     const int w = (spare && wave > 4) ? wave - 2 : wave - 1;   /* FIR wave index */
     const int fl = lane / QL, q = lane % QL;
     const int g = w * FWV + fl;             /* frame slot in the workgroup */
@@ -296,8 +304,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                 uint32_t packed = 0;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const float2 tq = zring[(size_t)row * DSTRIDE + slot + R * q + r];
-                    z[r] = apply_quadrant(tq.x, tq.y, qring[(size_t)row * (DR * S) + slot + R * q + r]);   /* qpsk.c:197 */
+                    const float4 tq = zring[(size_t)row * ZSTRIDE + slot + R * q + r];
+                    z[r] = apply_quadrant(tq.x, tq.y, __float_as_uint(tq.z));   /* qpsk.c:197 */
                     packed |= (uint32_t)slicer(z[r]) << (8 * r);   /* qpsk_demod(), qpsk.c:74-79 */
                 }
                 if (R * q + R <= cnt && ((N | sym0) & 3) == 0) {
@@ -345,7 +353,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         /* sliding-window FIR: symbol r of this lane uses tap k = t - C*r at window position 32q + t */
         float2 acc[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = make_float2(0.0f, 0.0f);
+        for (int r = 0; r < R; r++) acc[r] = (a.dbg & 1) ? make_float2(0.7f, 0.3f) : make_float2(0.0f, 0.0f);
         /* t = C*tb + u: symbol r needs tap group tb - r (taps C*(tb-r) .. +C-1), so each group of C taps is
          * live for R consecutive blocks: group tb is fetched at block tb into slot tb % R */
         static_assert(C == 8 && R == 4, "tap group rotation below is written for C = 8, R = 4");
@@ -390,7 +398,7 @@ size_t pipe_lds_bytes(int NF, int nbw, bool want_costas)
 {
     const size_t G = (size_t)NF * FWV;
     (void)want_costas;
-    size_t b = sizeof(Smem) + sizeof(float2) * (G * WSLOTS + G * DSTRIDE + G * nbw * DSTRIDE) + G * nbw * (DR * S);
+    size_t b = sizeof(Smem) + sizeof(float2) * (G * WSLOTS + G * DSTRIDE) + sizeof(float4) * G * nbw * ZSTRIDE;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -403,7 +411,7 @@ int launch_rx_fused_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
     const int G = NF * FWV;
     const int blocks = (a.nframes + G - 1) / G;
     const size_t lds = pipe_lds_bytes(NF, a.nbw, a.costas != nullptr);
-    hipLaunchKernelGGL(rx_fused_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1 + ((a.dbg & 4) ? 1 : 0))), lds, s, a, status);
+    hipLaunchKernelGGL(rx_fused_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1 + ((NF == MAX_NF && !(a.dbg & 4)) ? 1 : 0))), lds, s, a, status);
     hipError_t e = hipGetLastError();
     return (int)e;
 }

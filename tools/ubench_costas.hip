@@ -13,11 +13,10 @@ using namespace qpsk;
 
 __global__ void k(const float2 *din, int nsym, float alpha, float beta, unsigned long long *out, float *state, int lanes, int usecpp)
 {
-    __shared__ float2 d[64 * 65];      // [lane][64+1]
-    __shared__ float2 z[64 * 65];
-    __shared__ unsigned char q[64 * 64];
+    __shared__ __attribute__((aligned(16))) float2 d[64 * 66];      // [lane][64+2]
+    __shared__ __attribute__((aligned(16))) float4 z[64 * 65];
     const int lane = threadIdx.x;
-    for (int i = lane; i < 64 * 65; i += blockDim.x) d[i] = din[i % 4096];
+    for (int i = lane; i < 64 * 66; i += blockDim.x) d[i] = din[i % 4096];
     __syncthreads();
     float ph = 0.1f * lane, fr = 0.13f;
     unsigned long long t0, t1, r0, r1;
@@ -26,19 +25,18 @@ __global__ void k(const float2 *din, int nsym, float alpha, float beta, unsigned
     if (lane < lanes) {
         for (int c = 0; c < nsym / 64; c++) {
             if (!usecpp) {
-                unsigned da = lds_addr(d + lane * 65), za = lds_addr(z + lane * 65), qa = lds_addr(q + lane * 64);
+                unsigned da = lds_addr(d + lane * 66), za = lds_addr(z + lane * 65);
                 unsigned long long fl;
                 unsigned left = 8;
                 while (left) {
-                    left = costas_asm_run(ph, fr, da, za, qa, left, alpha, beta, -1.0f, 1.0f, fl);
-                    if (left) { da += 64; za += 64; qa += 8; left--; }   // skip a flagged group (timing only)
+                    left = costas_asm_run(ph, fr, da, za, __builtin_amdgcn_readfirstlane(left), alpha, beta, -1.0f, 1.0f, fl);
+                    if (left) { da += 64; za += 128; left--; }   // skip a flagged group (timing only)
                 }
             } else {
                 for (int j = 0; j < 64; j++) {
                     float tx, ty; unsigned qq;
-                    costas_step_t<true>(ph, fr, alpha, beta, -1.0f, 1.0f, d[lane * 65 + j], tx, ty, qq);
-                    z[lane * 65 + j] = make_float2(tx, ty);
-                    q[lane * 64 + j] = (unsigned char)qq;
+                    costas_step_t<true>(ph, fr, alpha, beta, -1.0f, 1.0f, d[lane * 66 + j], tx, ty, qq);
+                    z[lane * 65 + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
                 }
             }
         }
