@@ -77,7 +77,10 @@ def cpu_baseline(x_host, taps):
     t0 = time.perf_counter()
     orc.rx_batch(x_host, FS, RS, timing_mode=TIMING_HIST, threads=1)
     dt1 = time.perf_counter() - t0
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))   # the cores this process may use (the box's CPU share)
+    except AttributeError:
+        ncores = os.cpu_count() or 1
     t0 = time.perf_counter()
     orc.rx_batch(x_host, FS, RS, timing_mode=TIMING_HIST, threads=ncores)
     dtn = time.perf_counter() - t0
@@ -111,28 +114,24 @@ def main():
     import torch
     import qpsk_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from qpsk_amd.shard import env_rank_world, init_distributed, max_over_ranks, shard_range
+    rank, local, world = env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libqpsk_hip has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist = init_distributed("nccl", dev)          # nccl == RCCL on ROCm; None when WORLD_SIZE == 1
     if not os.path.exists(qpsk_amd.lib_path()):
         if rank == 0:
             qpsk_amd.build()
         if dist:
             dist.barrier()
 
-    F = args.frames
+    # the job is world * args.frames independent frames; this rank demodulates its contiguous shard of them
+    lo, hi = shard_range(world * args.frames, rank, world)
+    F = hi - lo
     m = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX,
                        device=local)
-    # rank r owns frames [r*F, (r+1)*F) of the global batch (seeded by rank): independent shards, no exchange
     note("context ready, generating %d frames" % F)
     x = synth_frames_gpu(torch, dev, F, m.taps, seed=1000 + rank)
     torch.cuda.synchronize()
@@ -156,11 +155,7 @@ def main():
         m.rx_batch_raw(x, F, sym, freq, phase)
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
 
     # per-launch duration of the dominant kernel, HIP events on the launch stream (= torch's current stream)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -196,7 +191,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "batch %d frames x %d complex samples per GPU, 2400 baud, 8x oversample, fused RRC FIR + Costas + slicer, fixed timing offset %d (BASELINE configs[1])" % (F, L, FIXED_INDEX),
                    "frames_per_gpu": F, "frame_size": L, "fs": FS, "rs": RS, "loop_bw": "TAU/100", "sharding": "independent frames per GPU, no collective"},
-        "roofline": {"bound": "hbm", "kernel": "rx_fused_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "rx_fused_pipe_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * F * L},
     }

@@ -19,7 +19,7 @@ ORACLE_SO = os.path.join(HERE, "libqpsk_oracle.so")
 REF_DIR = os.path.join(HERE, "_ref")
 
 TAU = 2.0 * 3.14159265358979323846
-TIMING_HIST, TIMING_FIXED = 0, 1
+TIMING_HIST, TIMING_FIXED, TIMING_FFT = 0, 1, 2
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -66,6 +66,7 @@ class Oracle:
                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.qo_demod.argtypes = [C.c_float, C.c_float]
         L.qo_timing_index.argtypes = [_f32p, C.c_int, C.c_int]
+        L.qo_timing_fft_index.argtypes = [_f32p, _f32p, C.c_int, C.c_int]
         L.qo_modem_new.argtypes = [C.c_double, C.c_double, C.c_int, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_int, C.c_int]
         L.qo_modem_new.restype = C.c_void_p
@@ -104,6 +105,10 @@ class Oracle:
 
     def timing_index(self, filtered, cycles):
         return self.lib.qo_timing_index(filtered.reshape(-1), filtered.size // 2, cycles)
+
+    def timing_fft_index(self, taps, frame, cycles):
+        return self.lib.qo_timing_fft_index(np.ascontiguousarray(taps, np.float32), np.ascontiguousarray(frame, np.float32).reshape(-1),
+                                            frame.size // 2, cycles)
 
     def sincosf(self, x):
         s, c = C.c_float(), C.c_float()

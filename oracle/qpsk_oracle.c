@@ -232,6 +232,41 @@ int qo_timing_index(const float *x, int frame_size, int cycles)
     return index;
 }
 
+/* FFT timing estimate (NEW DESIGN, no reference counterpart -- parity unpinned by the reference; the
+ * transform underneath is the pinned qo_fftn()).  Definition: qpsk_amd/csrc/timing_fft.hip.
+ * x = one fresh frame (before the FIR), L samples. */
+int qo_timing_fft_index(const float *taps, const float *x, int L, int cycles)
+{
+    enum { N0 = 128, NFFT = 512 };
+    float w[2 * QO_NTAPS];
+    double *p = calloc(2 * NFFT, sizeof(double)), *X = calloc(2 * NFFT, sizeof(double));
+    for (int m = 0; m < NFFT; m++) {
+        const int n = N0 + m;
+        /* window of the fresh delay line at sample n: x[n-126 .. n], zeros past the end of the frame */
+        for (int k = 0; k < QO_NTAPS; k++) {
+            const int s = n - (QO_NTAPS - 1) + k;
+            w[2 * k] = (s >= 0 && s < L) ? x[2 * s] : 0.0f;
+            w[2 * k + 1] = (s >= 0 && s < L) ? x[2 * s + 1] : 0.0f;
+        }
+        float yr, yi;
+        fir_point(taps, w, &yr, &yi);
+        const double pr = (double)yr * (double)yr, pi = (double)yi * (double)yi;
+        p[2 * m] = pr + pi;
+    }
+    qo_fftn(p, X, NFFT);
+    const double xr = X[2 * (NFFT / cycles)], xi = X[2 * (NFFT / cycles) + 1];
+    int best = 0;
+    double hmax = xr * cos(QO_TAU * 0.0 / (double)cycles) - xi * sin(QO_TAU * 0.0 / (double)cycles);
+    for (int i = 1; i < cycles; i++) {
+        const double a = QO_TAU * (double)i / (double)cycles;
+        const double c = xr * cos(a) - xi * sin(a);
+        if (c > hmax) { hmax = c; best = i; }
+    }
+    free(p);
+    free(X);
+    return best;
+}
+
 /* ----------------------------------------------------------------- modem */
 
 void qo_mixer_from_hz(double hz, double fs, float *rect2)
@@ -399,6 +434,8 @@ void qo_rx_batch_bw(double fs, double rs, int frame_size, float rrc_alpha, const
                     d[2 * i + 1] = src < L ? filt[2 * src + 1] : 0.0f;
                 }
             } else {
+                if (timing_mode == QO_TIMING_FFT)
+                    index = qo_timing_fft_index(taps, x, L, C);
                 fir_decimate_fresh(taps, x, L, C, index, N, d);
             }
             if (index_out) index_out[f] = index;
@@ -454,6 +491,8 @@ void qo_rx_batch(double fs, double rs, int frame_size, float rrc_alpha, float lo
                     d[2 * i + 1] = src < L ? filt[2 * src + 1] : 0.0f;
                 }
             } else {
+                if (timing_mode == QO_TIMING_FFT)
+                    index = qo_timing_fft_index(taps, x, L, C);
                 fir_decimate_fresh(taps, x, L, C, index, N, d);
             }
             if (index_out) index_out[f] = index;

@@ -28,7 +28,7 @@ extern "C" {
 #define QO_TAU (2.0 * QO_PI)    /* qpsk.h:29 */
 #define QO_ROT45 0x1.6a09e6p-1f /* cosf == sinf of (float)(M_PI/4), qpsk.h:30, qpsk.c:75 */
 
-enum { QO_TIMING_HIST = 0, QO_TIMING_FIXED = 1 };
+enum { QO_TIMING_HIST = 0, QO_TIMING_FIXED = 1, QO_TIMING_FFT = 2 };
 
 /* ---- RRC taps and FIR (rrc_fir.c) ---- */
 void qo_rrc_make(float fs, float rs, float alpha, float *taps);                       /* rrc_fir.c:32-76 */
@@ -62,6 +62,10 @@ int qo_demod(float re, float im);                                               
 
 /* ---- timing histogram (qpsk.c:90-108,127-180) on one filtered block ---- */
 int qo_timing_index(const float *filtered, int frame_size, int cycles);
+
+/* ---- FFT timing estimate: NOT in the reference (parity unpinned by it); definition in
+ * qpsk_amd/csrc/timing_fft.hip, restated here for the parity tests. x = one fresh frame BEFORE the FIR ---- */
+int qo_timing_fft_index(const float *taps, const float *x, int L, int cycles);
 
 /* ---- one modem instance: everything rx_frame() keeps in globals ---- */
 typedef struct {

@@ -303,6 +303,48 @@ static void pick_tiling(const qpsk_ctx *c, int nframes, int nbw, int *G, int *S)
     *S = s;
 }
 
+/* device copy of the size-n twiddle table (cos, sin)(TAU j/n), built once per n with the host's libm (fft.c:55-56) */
+static int get_twiddles(qpsk_ctx *c, int n, double **out)
+{
+    auto it = c->twiddles.find(n);
+    if (it != c->twiddles.end()) { *out = it->second; return QPSK_OK; }
+    const size_t cnt = n >= 2 ? (size_t)n / 2 : 1;
+    std::vector<double> h(2 * cnt, 0.0);
+    qpsk_host_twiddles(n, h.data());
+    double *tw = nullptr;
+    HIP_TRY(hipMalloc((void **)&tw, sizeof(double) * 2 * cnt));
+    HIP_TRY(hipMemcpy(tw, h.data(), sizeof(double) * 2 * cnt, hipMemcpyHostToDevice));
+    c->twiddles[n] = tw;
+    *out = tw;
+    return QPSK_OK;
+}
+
+static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index)
+{
+    const int C = c->cycles, nfft = timing_fft_nfft();
+    if (C < 2 || C > 8 || (C & (C - 1)))
+        return fail(QPSK_ERR_ARG, "QPSK_TIMING_FFT needs CYCLES in {2,4,8} (the symbol-rate bin NFFT/CYCLES must be exact and the offset < 8); CYCLES = %d", C);
+    if (c->prm.frame_size < timing_fft_first() + nfft)
+        return fail(QPSK_ERR_ARG, "QPSK_TIMING_FFT needs frame_size >= %d", timing_fft_first() + nfft);
+    double *tw = nullptr;
+    int rc = get_twiddles(c, nfft, &tw);
+    if (rc) return rc;
+    /* candidate phases (cos, sin)(TAU i/CYCLES): entry -C of the twiddle cache (key < 0 cannot collide with an FFT size) */
+    double *cs = nullptr;
+    auto it = c->twiddles.find(-C);
+    if (it == c->twiddles.end()) {
+        std::vector<double> full(2 * (size_t)C);
+        qpsk_host_phases(C, full.data());
+        HIP_TRY(hipMalloc((void **)&cs, sizeof(double) * 2 * C));
+        HIP_TRY(hipMemcpy(cs, full.data(), sizeof(double) * 2 * C, hipMemcpyHostToDevice));
+        c->twiddles[-C] = cs;
+    } else {
+        cs = it->second;
+    }
+    KERNEL_TRY(launch_timing_fft(d_in, nframes, c->prm.frame_size, C, c->d_taps, tw, cs, d_index, c->stream));
+    return QPSK_OK;
+}
+
 static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int32_t **d_index_out)
 {
     *d_index_out = nullptr;
@@ -319,7 +361,11 @@ static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int
         *d_index_out = (const int32_t *)c->index.p;
         return QPSK_OK;
     }
-    return fail(QPSK_ERR_ARG, "timing mode %d is not implemented in this build", c->prm.timing_mode);
+    /* QPSK_TIMING_FFT: symbol-rate line of |y|^2 through the reference's radix-2 FFT (timing_fft.hip) */
+    rc = fft_timing_indices(c, d_in, nframes, (int32_t *)c->index.p);
+    if (rc) return rc;
+    *d_index_out = (const int32_t *)c->index.p;
+    return QPSK_OK;
 }
 
 static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw, uint8_t *d_sym, float *d_freq,
@@ -455,17 +501,7 @@ int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, i
     int log2n = 0;
     while ((1 << log2n) < n) log2n++;
     double *tw = nullptr;
-    auto it = c->twiddles.find(n);
-    if (it == c->twiddles.end()) {
-        const size_t cnt = n >= 2 ? (size_t)n / 2 : 1;
-        std::vector<double> h(2 * cnt, 0.0);
-        qpsk_host_twiddles(n, h.data());
-        HIP_TRY(hipMalloc((void **)&tw, sizeof(double) * 2 * cnt));
-        HIP_TRY(hipMemcpy(tw, h.data(), sizeof(double) * 2 * cnt, hipMemcpyHostToDevice));
-        c->twiddles[n] = tw;
-    } else {
-        tw = it->second;
-    }
+    if (int rt = get_twiddles(c, n, &tw)) return rt;
     KERNEL_TRY(launch_fft(d_in, d_out, tw, nbatch, n, log2n, inverse ? 1 : 0, c->stream));
     return QPSK_OK;
 }

@@ -76,6 +76,16 @@ void qpsk_host_rect(double hz, double fs, float rect[2])
     rect[1] = s * -1.0f;
 }
 
+/* (cos, sin)(2 pi i / n) for i < n: the candidate timing phases of the FFT timing estimate (timing_fft.hip) */
+void qpsk_host_phases(int n, double *cs)
+{
+    for (int i = 0; i < n; i++) {
+        const double a = 2.0 * PI_D * (double)i / (double)n;
+        cs[2 * i] = cos(a);
+        cs[2 * i + 1] = sin(a);
+    }
+}
+
 void qpsk_host_twiddles(int n, double *tw)
 {
     for (int m = 0; m < n / 2; m++) {

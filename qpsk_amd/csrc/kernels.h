@@ -55,6 +55,11 @@ int launch_decimate(const float *filtered, const int32_t *index, float *dec, int
 int launch_mixer(const int16_t *pcm, float *out, float *state, int nstreams, int frame_size, hipStream_t s);
 int launch_fft(const double *in, double *out, const double *tw, int nbatch, int n, int log2n, int inverse,
                hipStream_t s);
+/* timing_fft.hip */
+int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
+                      const double *cs, int32_t *index, hipStream_t s);
+int timing_fft_nfft(void);
+int timing_fft_first(void);
 int launch_fill_i32(int32_t *p, int n, int32_t v, hipStream_t s);
 int launch_sincos_hash(uint32_t first, uint32_t count, unsigned long long *acc, hipStream_t s);
 

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "qpsk_device.h"
+#include "fft_lds.h"
 #include "kernels.h"
 
 namespace qpsk {
@@ -361,22 +362,7 @@ fft_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, const doub
         v[r] = src[i];
     }
     __syncthreads();
-    const double sgn = inverse ? 1.0 : -1.0;
-    for (int s = 1; s <= log2n; s++) {
-        const int half = 1 << (s - 1), stride = n >> s;
-        for (int b = tid; b < n / 2; b += blockDim.x) {
-            const int k = b & (half - 1);
-            const int lo = ((b >> (s - 1)) << s) + k, hi = lo + half;
-            const double2 w = tw[k * stride];
-            const double wr = w.x, wi = sgn * w.y;
-            const double2 e = v[lo], o = v[hi];
-            const double zr = wr * o.x - wi * o.y;
-            const double zi = wr * o.y + wi * o.x;
-            v[lo] = make_double2(e.x + zr, e.y + zi);
-            v[hi] = make_double2(e.x - zr, e.y - zi);
-        }
-        __syncthreads();
-    }
+    fft_lds_stages(v, tw, n, log2n, tid, (int)blockDim.x, inverse ? 1.0 : -1.0);
     const double dn = (double)n;
     for (int i = tid; i < n; i += blockDim.x) {
         double2 r = v[i];

@@ -100,6 +100,23 @@ def test_rx_batch_reference_timing(oracle, fs, rs, L, F):
     assert_batch_equal(got, want)
 
 
+@pytest.mark.parametrize("fs,rs,L,F", [(19200.0, 2400.0, 1024, 40), (19200.0, 2400.0, 16384, 6), (9600.0, 2400.0, 2048, 33)])
+def test_rx_batch_fft_timing(oracle, fs, rs, L, F):
+    """config 3: the FFT timing estimate (new design on top of the reference's radix-2 FFT) in front of the
+    fused kernel -- parity with the oracle's restatement of the same definition (unpinned by the reference)"""
+    from oracle.pyoracle import TIMING_FFT
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT)
+    x, _ = make_frames(F, L, m.cycles, m.taps, fs, offset_hz=20.0, base_seed=L + 1, noise=0.05)
+    x[-1] = random_frames(1, L, seed=2)[0]
+    x[-2] = 0.0
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FFT, want_costas=True)
+    got = m.rx_batch(x, want_costas=True)
+    m.sync()
+    assert_batch_equal(got, want)
+    # on clean modem frames the estimate is the eye centre: TX + RX group delay 126 samples = 126 mod CYCLES
+    assert np.all(want["index"][:F - 2] == 126 % m.cycles)
+
+
 def test_rx_batch_tilings_agree(oracle, monkeypatch):
     """results do not depend on how frames are grouped into workgroups / chunks"""
     fs, rs, L, F = 19200.0, 2400.0, 2048, 50

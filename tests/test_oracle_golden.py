@@ -77,6 +77,19 @@ def test_independent_frames(oracle, name):
         assert of["phase"][0] == g["phase"][f] and of["freq"][0] == g["freq"][f]
 
 
+def test_fft_timing_estimate_finds_the_eye_centre(oracle):
+    """The FFT timing estimate is a new design (the reference never calls its fft.c); its definition lives in
+    qpsk_amd/csrc/timing_fft.hip and the oracle restates it.  Sanity: on modem frames the symbol-rate line of
+    |y|^2 points at the sample offset where TX+RX root-raised-cosine filters peak (126 samples of group delay)."""
+    from sigutil import make_frames
+    for cycles, fs in ((8, 19200.0), (4, 9600.0)):
+        taps = oracle.rrc_make(fs, 2400.0, np.float32(.35))
+        for off in (0.0, 50.0, -120.0):
+            x, _ = make_frames(3, 1024, cycles, taps, fs, offset_hz=off, base_seed=int(off) + 5, noise=0.05)
+            for f in range(3):
+                assert oracle.timing_fft_index(taps, x[f], cycles) == 126 % cycles
+
+
 def test_fft_vectors(oracle):
     g = golden("fft_bits.npz")
     for n in (2, 8, 64, 512, 2048):
