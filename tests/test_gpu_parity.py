@@ -264,6 +264,51 @@ def test_fft_batch(oracle):
     assert np.all(cpu(m.fft(np.eye(1, 512, dtype=np.complex128)))[0] == 2.0 ** -9)
 
 
+# ------------------------------------------------------------------ the reference's own entry points (qpsk_dropin.h)
+def test_dropin_reference_signatures_golden():
+    """rrc_make / create_control_loop / rx_frame / rrc_fir / fft exactly as the reference's main() calls them
+    (qpsk.c:302,308,344-354), against the outputs recorded from the reference (tests/golden)."""
+    import qpsk_amd
+    from qpsk_amd.lib import Params
+    L = qpsk_amd.load()
+    g = golden("stream_pcm_shipped.npz")
+    p = Params()
+    L.qpsk_params_default(C.byref(p))
+    L.qpsk_dropin_configure.argtypes = [C.POINTER(Params), C.c_double]
+    assert L.qpsk_dropin_configure(C.byref(p), 1500.0) == 0
+    L.create_control_loop.argtypes = [C.c_float] * 3
+    L.rrc_make.argtypes = [C.c_float] * 3
+    L.create_control_loop(np.float32(g["loop_bw"]), -1.0, 1.0)
+    L.rrc_make(9600.0, 2400.0, 0.35)
+    for fn in ("get_phase", "get_frequency", "get_alpha", "get_beta", "qpsk_dropin_offset_freq"):
+        getattr(L, fn).restype = C.c_float
+    L.qpsk_dropin_costas_frame.restype = C.POINTER(C.c_float)
+    L.qpsk_dropin_symbols.restype = C.POINTER(C.c_uint8)
+    fs, N = 512, 128
+    for k in range(g["sym"].shape[0]):
+        blk = np.ascontiguousarray(g["pcm"][k * fs:(k + 1) * fs])
+        L.rx_frame(blk.ctypes.data_as(C.POINTER(C.c_int16)))
+        sym = np.ctypeslib.as_array(L.qpsk_dropin_symbols(), shape=(N,)).copy()
+        cf = np.ctypeslib.as_array(L.qpsk_dropin_costas_frame(), shape=(N, 2)).copy()
+        assert bits_equal(sym, g["sym"][k]) and bits_equal(cf, g["costas"][k]), k
+        assert np.float32(L.get_phase()) == g["phase"][k] and np.float32(L.get_frequency()) == g["freq"][k]
+        assert np.float32(L.qpsk_dropin_offset_freq()) == g["hz"][k] and L.qpsk_dropin_timing_index() == g["index"][k]
+    # rrc_fir(memory, sample, length) in place with a caller-owned delay line (rrc_fir.c:17-30)
+    gf = golden("fir.npz")
+    mem = gf["mem0"].copy()
+    for i in range(6):
+        y = gf["x%d" % i].copy()
+        L.rrc_fir(mem.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), y.shape[0])
+        assert bits_equal(y, gf["y%d" % i]) and bits_equal(mem, gf["m%d" % i]), i
+    # fft(in, out): NFFT = 512 (fft.h:44)
+    gb = golden("fft_bits.npz")
+    x = gb["x512"].copy()
+    out = np.zeros(512, np.complex128)
+    L.fft(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    np.testing.assert_allclose(out, gb["fft512"], rtol=0, atol=1e-15)
+    L.qpsk_dropin_shutdown()
+
+
 # ------------------------------------------------------------------ streams (consecutive rx_frame calls)
 @pytest.mark.parametrize("name", ["shipped", "c1small"])
 def test_streams_pcm_golden(name):
