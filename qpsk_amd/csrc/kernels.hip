@@ -163,27 +163,39 @@ size_t fused_lds_bytes(int G, int S, int cycles, int nbw)
 }
 
 /* ========================================================================
- * rrc_fir_kernel: full-rate FIR.  grid = (chunks, frames); each workgroup
- * produces FIR_TILE outputs of one delay line from FIR_TILE+126 staged
- * inputs; history before the block comes from the caller's delay line
- * (memory[1..126], memory[0] is shifted out by the first step, rrc_fir.c:19)
- * or is zero.
+ * rrc_fir_kernel: full-rate FIR (rrc_fir.c:17-30).  grid = (tiles, frames);
+ * a workgroup produces FIR_TILE = 2048 outputs of one delay line from
+ * 2048 + 126 staged inputs; history before the block comes from the
+ * caller's delay line (memory[1..126]; memory[0] is shifted out by the first
+ * step, rrc_fir.c:19) or is zero.
+ *
+ * VALU-bound (508 unfused fp32 operations per output), so the
+ * inner loop is a register sliding window: a lane produces FR = 8
+ * CONSECUTIVE outputs, one 8-byte LDS read feeds up to 8 multiply-add
+ * pairs (134 reads for 8 outputs instead of 8 x 127), each output's taps
+ * are still summed 0..126 in one fp32 accumulator.  Lanes are 8 samples
+ * apart; the LDS image puts sample position p at slot p + p/8, i.e. lanes
+ * 9 slots = 18 dwords apart: 32 lanes on 32 distinct even banks.  Taps come
+ * from LDS broadcast reads, two groups of 8 live at a time.  Outputs go back
+ * through the same padded image so that the global stores are coalesced.
  * ======================================================================== */
 constexpr int FIR_THREADS = 256;
-constexpr int FIR_PER_THREAD = 4;
-constexpr int FIR_TILE = FIR_THREADS * FIR_PER_THREAD;
+constexpr int FR = 8;
+constexpr int FIR_TILE = FIR_THREADS * FR;
+constexpr int FIR_WIN = FIR_TILE + HIST;
+constexpr int FIR_SLOTS = FIR_WIN + FIR_WIN / 8 + 1;
 
-__global__ void __launch_bounds__(FIR_THREADS)
+__global__ void __launch_bounds__(FIR_THREADS, 2)
 rrc_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ memory, float2 *__restrict__ y,
                const float *__restrict__ taps_g, int length)
 {
-    __shared__ float taps[128];
-    __shared__ float2 xs[FIR_TILE + HIST];
+    __shared__ __attribute__((aligned(16))) float taps[128];
+    __shared__ float2 xs[FIR_SLOTS];
     const int tid = threadIdx.x, f = blockIdx.y;
     const int n0 = blockIdx.x * FIR_TILE;
     if (tid < 128)
         taps[tid] = tid < NTAPS ? taps_g[tid] : 0.0f;
-    for (int i = tid; i < FIR_TILE + HIST; i += FIR_THREADS) {
+    for (int i = tid; i < FIR_WIN; i += FIR_THREADS) {
         const int n = n0 - HIST + i;
         float2 v = make_float2(0.0f, 0.0f);
         if (n >= 0) {
@@ -191,24 +203,53 @@ rrc_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ memory, 
         } else if (memory) {
             v = memory[(size_t)f * NTAPS + (NTAPS + n)]; /* n = -1 -> memory[126] */
         }
-        xs[i] = v;
+        xs[i + (i >> 3)] = v;
     }
     __syncthreads();
-    float2 acc[FIR_PER_THREAD];
+
+    /* output r of this lane = sample n0 + 8*tid + r = window position 8*tid + r + 126; its tap k sits at
+     * position 8*tid + r + k, so step t = r + k reads position 8*tid + t once for all r */
+    const float2 *rd = xs + 9 * tid;
+    const float4 *taps4 = reinterpret_cast<const float4 *>(taps);
+    float2 acc[FR];
 #pragma unroll
-    for (int r = 0; r < FIR_PER_THREAD; r++)
+    for (int r = 0; r < FR; r++)
         acc[r] = make_float2(0.0f, 0.0f);
-    for (int k = 0; k < NTAPS; k++) {
-        const float c = taps[k];
+    float tg[2][8];
 #pragma unroll
-        for (int r = 0; r < FIR_PER_THREAD; r++)
-            fir_mac(acc[r], xs[r * FIR_THREADS + tid + k], c);
+    for (int tb = 0; tb * 8 < NTAPS + FR - 1; tb++) {
+        if (tb * 8 < NTAPS) {
+            const float4 ta = taps4[2 * tb], tc = taps4[2 * tb + 1];
+            tg[tb & 1][0] = ta.x; tg[tb & 1][1] = ta.y; tg[tb & 1][2] = ta.z; tg[tb & 1][3] = ta.w;
+            tg[tb & 1][4] = tc.x; tg[tb & 1][5] = tc.y; tg[tb & 1][6] = tc.z; tg[tb & 1][7] = tc.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int t = tb * 8 + u;
+            if (t < NTAPS + FR - 1) {
+                const float2 v = rd[t + (t >> 3)];
+#pragma unroll
+                for (int r = 0; r < FR; r++) {
+                    const int k = t - r;
+                    if (k >= 0 && k < NTAPS) fir_mac(acc[r], v, tg[(k >> 3) & 1][k & 7]);
+                }
+            }
+        }
+        /* keep the scheduler from hoisting every later window read above this block (it would need ~470
+         * registers and leave one workgroup per CU with nothing to overlap its load/store phases with) */
+        __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();
+    /* transpose through LDS: lane-major results -> sample-major coalesced stores */
 #pragma unroll
-    for (int r = 0; r < FIR_PER_THREAD; r++) {
-        const int n = n0 + r * FIR_THREADS + tid;
+    for (int r = 0; r < FR; r++)
+        xs[9 * tid + r] = fir_gain(acc[r]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FR; j++) {
+        const int i = j * FIR_THREADS + tid, n = n0 + i;
         if (n < length)
-            y[(size_t)f * length + n] = fir_gain(acc[r]);
+            y[(size_t)f * length + n] = xs[i + (i >> 3)];
     }
 }
 
@@ -230,32 +271,94 @@ delay_line_kernel(const float2 *__restrict__ x, float2 *memory, int length)
 /* ========================================================================
  * timing_hist_kernel: qpsk.c:127-180.  The running average is never reset
  * (Q2) and the thresholds use the running maximum (Q3), so each component of
- * each frame is one serial scan: one lane per (frame, I|Q).
+ * each frame is one serial scan: one lane per (frame, I|Q), 16 frames per
+ * (single-wave) workgroup.  The filtered samples come through LDS in tiles
+ * of 64 samples per frame: all 64 lanes fetch one frame's tile with a
+ * coalesced 8-byte load (prefetched one tile ahead into registers), the 32
+ * scanning lanes then read their own row (row pitch 65 slots: the 32 lanes
+ * hit 32 different banks).
  * ======================================================================== */
+constexpr int TH_FRAMES = 16;
+constexpr int TH_TILE = 64;
+
 __global__ void __launch_bounds__(64)
 timing_hist_kernel(const float *__restrict__ y, int nframes, int frame_size, int cycles, int32_t *index)
 {
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    const int f = t >> 1, comp = t & 1;
-    int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (f < nframes) {
-        const float *p = y + (size_t)f * frame_size * 2 + comp;
-        float av = 0.0f, mx = 0.0f;
-        const float fc = (float)cycles;
-        for (int i = 0; i + cycles <= frame_size; i += cycles) {
-            for (int j = 0; j < cycles; j++)
-                av += fabsf(p[2 * (size_t)(i + j)]);
-            av = av / fc;
-            if (av > mx) mx = av;
-            const float hv = mx / 8.0f;
-            int k = 1;
-            for (; k < 8; k++)
-                if (av <= hv * (float)k) break;
-            /* no dynamic indexing of a private array: keep hist[] in registers */
+    __shared__ float2 tile[TH_FRAMES][TH_TILE + 1];
+    const int lane = threadIdx.x;
+    const int f0 = blockIdx.x * TH_FRAMES;
+    const int fl = (lane >> 1) & (TH_FRAMES - 1), comp = lane & 1;
+    const bool scanning = lane < 2 * TH_FRAMES && f0 + fl < nframes;
+    const float2 *y2 = reinterpret_cast<const float2 *>(y);
+    const int ntiles = (frame_size + TH_TILE - 1) / TH_TILE;
+
+    float2 pre[TH_FRAMES];
+    auto fetch = [&](int t) {
+        const int s = min(t * TH_TILE + lane, frame_size - 1);        /* clamped: past-the-end slots are never scanned */
 #pragma unroll
-            for (int q = 1; q < 8; q++)
-                hist[q] += (q == k) ? 1 : 0;
+        for (int r = 0; r < TH_FRAMES; r++)
+            pre[r] = y2[(size_t)min(f0 + r, nframes - 1) * frame_size + s];
+    };
+
+    int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float av = 0.0f, mx = 0.0f;
+    const float fc = (float)cycles;
+    int j = 0;                                  /* samples of the current symbol already added */
+    const float *row = reinterpret_cast<const float *>(&tile[fl][0]) + comp;
+    fetch(0);
+    for (int t = 0; t < ntiles; t++) {
+#pragma unroll
+        for (int r = 0; r < TH_FRAMES; r++)
+            tile[r][lane] = pre[r];
+        if (t + 1 < ntiles) fetch(t + 1);
+        __syncthreads();
+        if (scanning) {
+            const int cnt = min(TH_TILE, frame_size - t * TH_TILE);
+            /* one symbol's bookkeeping (qpsk.c:137-166); the bin is found without a data-dependent loop */
+            auto symbol_end = [&]() {
+                av = av / fc;
+                if (av > mx) mx = av;
+                const float hv = mx / 8.0f;
+                int k = 8;
+#pragma unroll
+                for (int q = 7; q >= 1; q--)
+                    if (av <= hv * (float)q) k = q;          /* the first q that holds wins */
+#pragma unroll
+                for (int q = 1; q < 8; q++)
+                    hist[q] += (q == k) ? 1 : 0;
+            };
+            if (cycles == 8 && cnt == TH_TILE && j == 0) {
+                /* whole symbols inside the tile: fetch a symbol's 8 samples, then the 8 ordered adds */
+#pragma unroll 2
+                for (int sy = 0; sy < TH_TILE / 8; sy++) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = row[2 * (sy * 8 + u)];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) av += fabsf(v[u]);
+                    symbol_end();
+                }
+            } else if (cycles == 4 && cnt == TH_TILE && j == 0) {
+#pragma unroll 2
+                for (int sy = 0; sy < TH_TILE / 4; sy++) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = row[2 * (sy * 4 + u)];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) av += fabsf(v[u]);
+                    symbol_end();
+                }
+            } else {
+                for (int i = 0; i < cnt; i++) {
+                    av += fabsf(row[2 * i]);
+                    if (++j == cycles) {
+                        j = 0;
+                        symbol_end();
+                    }
+                }
+            }
         }
+        __syncthreads();
     }
     /* lanes 2f and 2f+1 hold hist_i and hist_q of frame f: integer add across the pair */
     int hmax = 0, best = 0;
@@ -264,8 +367,8 @@ timing_hist_kernel(const float *__restrict__ y, int nframes, int frame_size, int
         const int h = hist[q] + __shfl_xor(hist[q], 1);
         if (h > hmax) { hmax = h; best = q; }
     }
-    if (f < nframes && comp == 0)
-        index[f] = best;
+    if (scanning && comp == 0)
+        index[f0 + fl] = best;
 }
 
 /* ========================================================================
@@ -442,9 +545,8 @@ int launch_delay_line(const float *x, float *memory, int nframes, int length, hi
 
 int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, hipStream_t s)
 {
-    const int threads = nframes * 2;
-    hipLaunchKernelGGL(timing_hist_kernel, dim3((threads + 63) / 64), dim3(64), 0, s, y, nframes, frame_size,
-                       cycles, index);
+    hipLaunchKernelGGL(timing_hist_kernel, dim3((nframes + TH_FRAMES - 1) / TH_FRAMES), dim3(64), 0, s, y, nframes,
+                       frame_size, cycles, index);
     LAUNCH_CHECK();
     return 0;
 }

@@ -21,14 +21,15 @@ def main():
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--per-round", type=int, default=4)
+    ap.add_argument("--timing", choices=["fixed", "hist", "fft"], default="fixed")
     ap.add_argument("configs", nargs="*", default=[""])
     args = ap.parse_args()
     import torch
     import qpsk_amd
     dev = torch.device("cuda", 0)
     F = args.frames
-    m = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=qpsk_amd.TIMING_FIXED,
-                       fixed_index=bench.FIXED_INDEX)
+    mode = {"fixed": qpsk_amd.TIMING_FIXED, "hist": qpsk_amd.TIMING_HIST, "fft": qpsk_amd.TIMING_FFT}[args.timing]
+    m = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=mode, fixed_index=bench.FIXED_INDEX)
     x = bench.synth_frames_gpu(torch, dev, F, m.taps, seed=1000)
     sym = torch.empty((F, m.nsym), dtype=torch.uint8, device=dev)
     freq = torch.empty((F,), dtype=torch.float32, device=dev)
