@@ -171,6 +171,69 @@ def test_loop_bandwidth_sweep(oracle):
     assert bits_equal(cpu(one["sym"]), want["sym"][:, 0]) and bits_equal(cpu(one["freq"]), want["freq"][:, 0])
 
 
+def test_full_size_config2_properties(oracle):
+    """BASELINE config 2 at full size (4096 frames x 16384 samples, 512 MiB): the oracle cannot run all of it
+    in seconds, so: (a) a spread sample of frames is compared with the oracle bit for bit, (b) a second launch
+    reproduces every output bit, (c) frames are independent: reversing the batch reverses the outputs,
+    (d) every frame's loop ends on the +50 Hz offset the generator applied (qpsk.c:320 vs 342)."""
+    import torch
+    import bench
+    fs, rs, L, F = bench.FS, bench.RS, 16384, 4096
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=bench.FIXED_INDEX)
+    x = bench.synth_frames_gpu(torch, torch.device("cuda", 0), F, m.taps, seed=7)
+    a = m.rx_batch(x)
+    m.sync()
+    pick = np.unique(np.concatenate([np.arange(0, F, 97), [1, 15, 16, 17, F - 17, F - 16, F - 1]]))
+    want = oracle.rx_batch(x[torch.from_numpy(pick).cuda()].cpu().numpy(), fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED,
+                           fixed_index=bench.FIXED_INDEX)
+    for k in ("sym", "phase", "freq", "hz"):
+        assert bits_equal(cpu(a[k])[pick], want[k]), k
+    b = m.rx_batch(x)
+    m.sync()
+    for k in ("sym", "phase", "freq"):
+        assert bits_equal(cpu(a[k]), cpu(b[k])), k
+    r = m.rx_batch(torch.flip(x, dims=[0]).contiguous())
+    m.sync()
+    for k in ("sym", "phase", "freq"):
+        assert bits_equal(cpu(a[k]), cpu(r[k])[::-1].copy()), k
+    assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
+
+
+def test_empty_and_bad_calls_are_rejected():
+    import torch
+    m = modem(fs=19200.0, rs=2400.0, frame_size=1024)
+    x = torch.zeros((1, 1024, 2), dtype=torch.float32, device="cuda")
+    sym = torch.zeros((1, 128), dtype=torch.uint8, device="cuda")
+    L = m.L
+    assert L.qpsk_rx_batch(m.h, C.c_void_p(x.data_ptr()), 0, C.c_void_p(sym.data_ptr()), None, None, None, None, None) == -2
+    assert b"nframes" in L.qpsk_last_error()
+    assert L.qpsk_rx_batch(m.h, None, 1, C.c_void_p(sym.data_ptr()), None, None, None, None, None) == -2
+    assert L.qpsk_fft_batch(m.h, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), 1, 24, 0) == -2      # not a power of two
+    assert L.qpsk_streams_rx_cplx(m.h, C.c_void_p(x.data_ptr()), None, None, None, None, None) == -5    # no qpsk_streams_reset yet
+    import qpsk_amd
+    with pytest.raises(qpsk_amd.QpskError):
+        qpsk_amd.Modem(fs=9600.0, rs=2400.0, frame_size=510)                                              # 510 % 4 != 0
+    with pytest.raises(qpsk_amd.QpskError):
+        qpsk_amd.Modem(fs=19200.0, rs=2400.0, frame_size=1024, timing_mode=TIMING_FIXED, fixed_index=9)
+
+
+def test_config5_long_frames_bandwidth_sweep(oracle):
+    """BASELINE config 5 at its real frame length: 1200 baud, 8x oversample, 1,048,576 samples per frame
+    (131,072 serial Costas steps), loop bandwidths TAU/100 .. TAU/200 sharing one FIR pass; a handful of
+    frames (the frame COUNT is the only thing reduced: the oracle needs ~1 s per frame)."""
+    fs, rs, L, F = 9600.0, 1200.0, 1 << 20, 5
+    bws = [np.float32(TAU / d) for d in range(100, 201, 10)]
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=3.0, base_seed=55, noise=0.02)
+    want = oracle.rx_batch_bw(x, fs, rs, bws, timing_mode=TIMING_FIXED, fixed_index=6)
+    got = m.rx_batch_bw(x, bws)
+    m.sync()
+    assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
+    # every loop of the sweep has locked onto the 3 Hz offset by the end of such a frame (README.md:12)
+    hz = cpu(got["freq"]).astype(np.float64) * rs / (2 * np.pi)
+    assert np.all(np.abs(hz - 3.0) < 0.5)
+
+
 # ------------------------------------------------------------------ stages
 def test_rrc_fir_batch_with_delay_lines(oracle):
     import torch
