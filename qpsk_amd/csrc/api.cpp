@@ -451,6 +451,40 @@ int qpsk_rx_batch_bw(qpsk_ctx *c, const float *d_in, int nframes, const float *h
     return rx_batch_common(c, d_in, nframes, nbw, d_sym, d_freq, d_phase, nullptr, d_index, nullptr);
 }
 
+/* Costas + slicer over decimated symbols already in device memory (qpsk.c:196-212): the pipeline kernel with
+ * loader waves in place of the FIR waves; the one-lane-per-frame kernel only when QPSK_FUSED_GENERIC is set. */
+static int costas_over_symbols(qpsk_ctx *c, const float *d_symbols, int nframes, int nsym, int dstride, float *d_state,
+                               uint8_t *d_sym, float *d_costas)
+{
+    if (env_int("QPSK_FUSED_GENERIC", 0)) {
+        KERNEL_TRY(launch_costas(d_symbols, nframes, nsym, dstride, 1, c->d_gains, c->min_freq, c->max_freq, d_state, d_state,
+                                 d_sym, d_costas, c->stream));
+        return QPSK_OK;
+    }
+    FusedArgs a{};
+    a.nframes = nframes;
+    a.nsym = nsym;
+    a.frame_size = nsym * c->cycles;
+    a.cycles = c->cycles;
+    a.gains = c->d_gains;
+    a.nbw = 1;
+    a.min_freq = c->min_freq;
+    a.max_freq = c->max_freq;
+    a.rs = c->prm.rs;
+    a.state_in = d_state;
+    a.state_out = d_state;
+    a.sym = d_sym;
+    a.costas = reinterpret_cast<float2 *>(d_costas);
+    a.dsrc = reinterpret_cast<const float2 *>(d_symbols);
+    a.dstride = dstride;
+    a.dbg = env_int("QPSK_PIPE_DBG", 0);
+    int nf = (nframes + 256 * pipe_frames_per_wave() - 1) / (256 * pipe_frames_per_wave());
+    if (nf < 1) nf = 1;
+    if (nf > pipe_max_nf()) nf = pipe_max_nf();
+    KERNEL_TRY(launch_costas_pipe(a, nf, c->d_status, c->stream));
+    return QPSK_OK;
+}
+
 /* ---------------------------------------------------------------- stages */
 int qpsk_rrc_fir_batch(qpsk_ctx *c, float *d_memory, const float *d_in, float *d_out, int nframes, int length)
 {
@@ -487,9 +521,7 @@ int qpsk_costas_batch(qpsk_ctx *c, const float *d_symbols_in, int nframes, int n
     if (nframes <= 0 || nsym <= 0) return fail(QPSK_ERR_ARG, "nframes %d nsym %d", nframes, nsym);
     if (bind(c)) return QPSK_ERR_HIP;
     if (int rg = use_context_gains(c)) return rg;
-    KERNEL_TRY(launch_costas(d_symbols_in, nframes, nsym, nsym, 1, c->d_gains, c->min_freq, c->max_freq, d_state, d_state,
-                             d_sym, d_costas, c->stream));
-    return QPSK_OK;
+    return costas_over_symbols(c, d_symbols_in, nframes, nsym, nsym, d_state, d_sym, d_costas);
 }
 
 int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, int n, int inverse)
@@ -585,8 +617,8 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
     KERNEL_TRY(launch_decimate(filt, idx, c->s_dec, n, L, c->cycles, N, c->stream));
     /* qpsk.c:196-212 over the lower half (= the previous block) */
     if (int rg = use_context_gains(c)) return rg;
-    KERNEL_TRY(launch_costas(c->s_dec, n, N, 2 * N, 1, c->d_gains, c->min_freq, c->max_freq, c->s_loop, c->s_loop, d_sym,
-                             d_costas, c->stream));
+    rc = costas_over_symbols(c, c->s_dec, n, N, 2 * N, c->s_loop, d_sym, d_costas);
+    if (rc) return rc;
     if (d_index) HIP_TRY(hipMemcpyAsync(d_index, idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
     if (d_phase) HIP_TRY(hipMemcpy2DAsync(d_phase, sizeof(float), c->s_loop, 2 * sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, c->stream));
     if (d_freq) HIP_TRY(hipMemcpy2DAsync(d_freq, sizeof(float), c->s_loop + 1, 2 * sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, c->stream));

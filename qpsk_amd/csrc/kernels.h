@@ -20,6 +20,8 @@ struct FusedArgs {
     const int32_t *index;   /* [nframes] or NULL -> fixed_index */
     int fixed_index;
     int dbg;                /* measurement only: 1 = skip FIR arithmetic, 2 = skip the Costas recurrence */
+    const float2 *dsrc;     /* costas_pipe_kernel only: decimated symbols, rows dstride symbols apart */
+    int dstride;
     const float *taps;      /* [127] */
     const float *gains;     /* [nbw][2] alpha, beta */
     int nbw;
@@ -43,6 +45,7 @@ int pipe_cycles(void);
 int pipe_max_nf(void);
 int prepare_pipe_kernel(void);
 int launch_rx_fused_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s);
+int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s);
 int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s);

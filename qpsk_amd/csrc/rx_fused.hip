@@ -11,16 +11,20 @@
  *     per ~5 cycles, dependent ones every ~8, so a frame's 2048 symbols cost
  *     2048 x (instructions per step) x 5 cycles however many CUs idle.
  * So each workgroup is a producer/consumer pipeline in LDS:
- *   wave 0           Costas + slicer, one lane per (frame, loop), never waits for HBM;
- *   waves 1..NF      FIR: each owns 4 frames outright (loads, history, filter),
- *                    so FIR waves never synchronise with each other, only with
- *                    wave 0 through two monotonic counters in LDS.
+ *   wave 0           the Costas recurrence (costas_asm.h), one lane per (frame, loop); it never waits
+ *                    for HBM and leaves 16-byte records (T.x, T.y, n, -) in an LDS ring;
+ *   FIR waves        each owns 4 frames outright (loads, history, filter, and the flush of its frames'
+ *                    records: de-rotation to costas_frame[], slicer, coalesced stores), so FIR waves
+ *                    never synchronise with each other, only with wave 0 through two monotonic
+ *                    counters in LDS (bounded spins; a timeout is reported through *status);
+ *   wave 4           (only when there are 4 FIR waves) exits at once, so that wave 0 does not share a SIMD.
  *
  * FIR wave layout: lane = (frame f of 4) x (q of 16); per chunk of S = 64
  * symbols the lane produces the R = 4 consecutive symbols 4q..4q+3 of its
  * frame with a sliding window: one 8-byte LDS read feeds up to 4 of the 508
- * multiply-adds, the 127 taps live in VGPRs, each symbol's taps are summed
- * 0..126 in one fp32 accumulator (bit-exactness).
+ * multiply-adds, taps come from LDS broadcast reads (4 groups of 8 live at a
+ * time), each symbol's taps are summed 0..126 in one fp32 accumulator
+ * (bit-exactness).
  * LDS image of a frame's window: position p (0 = the oldest sample the
  * chunk needs, i.e. sample chunk_start + index - 126) at float2 slot
  * p + p/32; lanes of one frame are 32 samples apart -> 33 slots -> the 16 x 2
@@ -96,6 +100,219 @@ __device__ __forceinline__ bool wait_ge(int *p, int target, int *abort_flag)
 
 using namespace pipe;
 
+/*
+ * The serial wave: one lane per (frame, loop).  It waits for chunk c of its frame in the symbol ring (counter
+ * ready[]), advances the loop over the chunk's symbols and leaves one 16-byte record per symbol in the record
+ * ring, then publishes consumed = c + 1.  Shared by rx_fused_pipe_kernel (ring fed by FIR waves) and
+ * costas_pipe_kernel (ring fed from already decimated symbols in global memory).
+ */
+__device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const float2 *dring, float4 *zring, int G,
+                                            int f0, int lane, int nchunks, int *status)
+{
+    const int nbw = a.nbw, N = a.nsym;
+    /* =============================== Costas + slicer wave ===================================== */
+    __builtin_amdgcn_s_setprio(3);
+    const int g = lane / nbw, b = lane - g * nbw;
+    const bool active = lane < G * nbw && f0 + g < a.nframes;
+    Loop st = {0.0f, 0.0f};
+    LoopGains lg = {0.0f, 0.0f, a.min_freq, a.max_freq};
+    if (active) {
+        lg.alpha = a.gains[2 * b];
+        lg.beta = a.gains[2 * b + 1];
+        if (a.state_in) {
+            st.phase = a.state_in[2 * ((size_t)(f0 + g) * nbw + b)];
+            st.freq = a.state_in[2 * ((size_t)(f0 + g) * nbw + b) + 1];
+        }
+    }
+    const int gw = (lane < G * nbw ? g : 0) / FWV;       /* the FIR wave that feeds this lane */
+    const float2 *dl = dring + (size_t)(lane < G * nbw ? g : 0) * DSTRIDE;
+    float4 *zl = zring + (size_t)lane * ZSTRIDE;
+    /* one median-of-3 instead of two compare/select pairs when the clamp is the usual min < 0 < max */
+    const bool fast_clamp = a.min_freq < 0.0f && a.max_freq > 0.0f;
+    float ph = st.phase, fr = st.freq;
+    const float al = lg.alpha, be = lg.beta, fmin_ = a.min_freq, fmax_ = a.max_freq;
+    bool ok = true;
+    for (int c = 0; c < nchunks && ok; c++) {
+        ok = wait_ge(&sm->ready[gw], c + 1, &sm->abort_flag);
+        if (!__all(ok)) { ok = false; break; }
+        const int slot = (c % DR) * S;
+        const int cnt = min(S, N - c * S);
+        if (active && !(a.dbg & 2)) { /* ablation knob (QPSK_PIPE_DBG bit 1): skip the recurrence */
+            int j = 0;
+            if (c == 0) { /* a loaded phase may be -0: first step with the form that is exact there too */
+                Loop s0 = {ph, fr};
+                const float2 z0 = costas_step<true>(s0, lg, dl[slot]);
+                zl[slot] = make_float4(z0.x, z0.y, 0.0f, 0.0f);   /* already de-rotated: quadrant 0 */
+                ph = s0.phase; fr = s0.freq;
+                j = 1;
+                if (cnt > 1) {   /* the stream below starts on an even symbol (16-byte aligned pair reads) */
+                    float tx, ty; unsigned qq;
+                    if (fast_clamp) costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + 1], tx, ty, qq);
+                    else costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dl[slot + 1], tx, ty, qq);
+                    zl[slot + 1] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
+                    j = 2;
+                }
+            }
+            /* the wave only advances the loop and leaves (T, quadrant); de-rotation to z, the slicer and
+             * costas_frame[] happen in the FIR waves' flush */
+            /* the next symbol is fetched from LDS one whole step ahead, so the recurrence never waits for
+             * the LDS pipe (which the FIR waves keep busy); reading one slot past the chunk is harmless
+             * (next slot or the row's padding element) */
+            if (fast_clamp && !(a.dbg & 8)) {
+                /* groups of 8 steps in the hand-scheduled stream (costas_asm.h); a group it abandons
+                 * (exact-zero detector input, double wrap) is redone here with the C++ step */
+                while (cnt - j >= 8) {
+                    unsigned da = lds_addr(dl + slot + j), za = lds_addr(zl + slot + j);
+                    unsigned long long fl;
+                    const unsigned want = __builtin_amdgcn_readfirstlane((unsigned)(cnt - j) / 8);   /* wave-uniform */
+                    const unsigned left = costas_asm_run(ph, fr, da, za, want, al, be, fmin_, fmax_, fl);
+                    j += 8 * (int)(want - left);
+                    if (left != 0) {
+                        for (int i = 0; i < 8; i++, j++) {
+                            float tx, ty; unsigned qq;
+                            costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
+                            zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
+                        }
+                    }
+                }
+            }
+            float2 dcur = dl[slot + j];
+            if (fast_clamp) {
+#pragma unroll 1
+                for (; j < cnt; j++) {
+                    const float2 dnext = dl[slot + j + 1];
+                    float tx, ty; unsigned qq;
+                    costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
+                    zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
+                    dcur = dnext;
+                }
+            } else {
+#pragma unroll 4
+                for (; j < cnt; j++) {
+                    const float2 dnext = dl[slot + j + 1];
+                    float tx, ty; unsigned qq;
+                    costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
+                    zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
+                    dcur = dnext;
+                }
+            }
+        }
+        if (lane == 0) st_release(&sm->consumed, c + 1);
+    }
+    st.phase = ph; st.freq = fr;
+    if (active && ok) {
+        const size_t o = (size_t)(f0 + g) * nbw + b;
+        if (a.freq) a.freq[o] = st.freq;
+        if (a.phase) a.phase[o] = st.phase;
+        if (a.hz) a.hz[o] = (float)((double)st.freq * a.rs / TAU); /* qpsk.c:217 */
+        if (a.state_out) { a.state_out[2 * o] = st.phase; a.state_out[2 * o + 1] = st.freq; }
+    }
+    if (!ok && lane == 0) atomicExch(status, 1);
+}
+
+/*
+ * Flush of one consumed chunk for one frame by its 16 lanes (lane q owns symbols 4q..4q+3 of the chunk):
+ * record (T, n) -> z = T (-j)^(n&3) = costas_frame[] (qpsk.c:197), slicer (qpsk.c:74-79), 4 symbols per
+ * 32-bit store.
+ */
+__device__ __forceinline__ void flush_records(const FusedArgs &a, const float4 *zring, int g, int frame, int q, int chunk)
+{
+    const int nbw = a.nbw, N = a.nsym;
+    const int slot = (chunk % DR) * S, sym0 = chunk * S;
+    const int cnt = min(S, N - sym0);
+    for (int b = 0; b < nbw; b++) {
+        const int row = g * nbw + b;
+        const size_t o = ((size_t)frame * nbw + b) * N + sym0 + R * q;
+        float2 z[R];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float4 tq = zring[(size_t)row * ZSTRIDE + slot + R * q + r];
+            z[r] = apply_quadrant(tq.x, tq.y, __float_as_uint(tq.z));
+            packed |= (uint32_t)slicer(z[r]) << (8 * r);
+        }
+        if (a.sym) {
+            if (R * q + R <= cnt && ((N | sym0) & 3) == 0) {
+                *reinterpret_cast<uint32_t *>(a.sym + o) = packed;
+            } else {
+                for (int r = 0; r < R; r++)
+                    if (R * q + r < cnt) a.sym[o + r] = (uint8_t)(packed >> (8 * r));
+            }
+        }
+        if (a.costas) {
+            for (int r = 0; r < R; r++)
+                if (R * q + r < cnt) a.costas[o + r] = z[r];
+        }
+    }
+}
+
+/* ========================================================================
+ * costas_pipe_kernel: the same pipeline with ALREADY DECIMATED symbols as
+ * input (qpsk.c:196-212 alone: qpsk_costas_batch, and the streaming mode,
+ * where decimated_frame[] carries the previous block, qpsk.c:186-197).
+ * Waves 1..NF only move data: 64 symbols per frame per chunk from global
+ * memory into the symbol ring, and the flush of consumed records.
+ * a.dsrc rows are a.dstride symbols apart; one loop per frame (nbw = 1).
+ * ======================================================================== */
+__global__ void __launch_bounds__(64 * (MAX_NF + 1))
+costas_pipe_kernel(FusedArgs a, int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem *sm = reinterpret_cast<Smem *>(smem_raw);
+    const int NF = (int)blockDim.x / 64 - 1;
+    const int G = NF * FWV;
+    float2 *dring = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));     /* [G][DSTRIDE] */
+    float4 *zring = reinterpret_cast<float4 *>(dring + (size_t)G * DSTRIDE);  /* [G][ZSTRIDE] */
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N = a.nsym;
+    const int f0 = blockIdx.x * G;
+    const int nchunks = (N + S - 1) / S;
+    if (tid < MAX_NF) sm->ready[tid] = 0;
+    if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
+    __syncthreads();
+
+    if (wave == 0) {
+        costas_wave(a, sm, dring, zring, G, f0, lane, nchunks, status);
+        return;
+    }
+    const int w = wave - 1;
+    const int fl = lane / QL, q = lane % QL;
+    const int g = w * FWV + fl;
+    const int frame = f0 + g;
+    const bool fvalid = frame < a.nframes;
+    const float2 *src = a.dsrc + (size_t)(fvalid ? frame : 0) * a.dstride;
+    int flushed = 0;
+    bool ok = true;
+    float2 pre[R];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            pre[r] = src[min(c * S + R * q + r, N - 1)];     /* clamped: symbols past N are never consumed */
+    };
+    fetch(0);
+    for (int c = 0; c < nchunks; c++) {
+        if (c >= DR) {
+            ok = wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag);
+            if (!ok) break;
+            for (; flushed < c - DR + 1; flushed++)
+                if (fvalid) flush_records(a, zring, g, frame, q, flushed);
+        }
+        float2 *dw = dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            dw[r] = pre[r];
+        if (c + 1 < nchunks) fetch(c + 1);
+        if (lane == 0) st_release(&sm->ready[w], c + 1);
+    }
+    if (ok) {
+        ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
+        if (ok)
+            for (; flushed < nchunks; flushed++)
+                if (fvalid) flush_records(a, zring, g, frame, q, flushed);
+    }
+    if (!ok && lane == 0) atomicExch(status, 1);
+}
+
 __global__ void __launch_bounds__(64 * (MAX_NF + 2))
 rx_fused_pipe_kernel(FusedArgs a, int *status)
 {
@@ -128,104 +345,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     __syncthreads();
 
     if (wave == 0) {
-        /* =============================== Costas + slicer wave ===================================== */
-        __builtin_amdgcn_s_setprio(3);
-        const int g = lane / nbw, b = lane - g * nbw;
-        const bool active = lane < G * nbw && f0 + g < a.nframes;
-        Loop st = {0.0f, 0.0f};
-        LoopGains lg = {0.0f, 0.0f, a.min_freq, a.max_freq};
-        if (active) {
-            lg.alpha = a.gains[2 * b];
-            lg.beta = a.gains[2 * b + 1];
-            if (a.state_in) {
-                st.phase = a.state_in[2 * ((size_t)(f0 + g) * nbw + b)];
-                st.freq = a.state_in[2 * ((size_t)(f0 + g) * nbw + b) + 1];
-            }
-        }
-        const int gw = (lane < G * nbw ? g : 0) / FWV;       /* the FIR wave that feeds this lane */
-        const float2 *dl = dring + (size_t)(lane < G * nbw ? g : 0) * DSTRIDE;
-        float4 *zl = zring + (size_t)lane * ZSTRIDE;
-        /* one median-of-3 instead of two compare/select pairs when the clamp is the usual min < 0 < max */
-        const bool fast_clamp = a.min_freq < 0.0f && a.max_freq > 0.0f;
-        float ph = st.phase, fr = st.freq;
-        const float al = lg.alpha, be = lg.beta, fmin_ = a.min_freq, fmax_ = a.max_freq;
-        bool ok = true;
-        for (int c = 0; c < nchunks && ok; c++) {
-            ok = wait_ge(&sm->ready[gw], c + 1, &sm->abort_flag);
-            if (!__all(ok)) { ok = false; break; }
-            const int slot = (c % DR) * S;
-            const int cnt = min(S, N - c * S);
-            if (active && !(a.dbg & 2)) { /* ablation knob (QPSK_PIPE_DBG bit 1): skip the recurrence */
-                int j = 0;
-                if (c == 0) { /* a loaded phase may be -0: first step with the form that is exact there too */
-                    Loop s0 = {ph, fr};
-                    const float2 z0 = costas_step<true>(s0, lg, dl[slot]);
-                    zl[slot] = make_float4(z0.x, z0.y, 0.0f, 0.0f);   /* already de-rotated: quadrant 0 */
-                    ph = s0.phase; fr = s0.freq;
-                    j = 1;
-                    if (cnt > 1) {   /* the stream below starts on an even symbol (16-byte aligned pair reads) */
-                        float tx, ty; unsigned qq;
-                        if (fast_clamp) costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + 1], tx, ty, qq);
-                        else costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dl[slot + 1], tx, ty, qq);
-                        zl[slot + 1] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
-                        j = 2;
-                    }
-                }
-                /* the wave only advances the loop and leaves (T, quadrant); de-rotation to z, the slicer and
-                 * costas_frame[] happen in the FIR waves' flush */
-                /* the next symbol is fetched from LDS one whole step ahead, so the recurrence never waits for
-                 * the LDS pipe (which the FIR waves keep busy); reading one slot past the chunk is harmless
-                 * (next slot or the row's padding element) */
-                if (fast_clamp && !(a.dbg & 8)) {
-                    /* groups of 8 steps in the hand-scheduled stream (costas_asm.h); a group it abandons
-                     * (exact-zero detector input, double wrap) is redone here with the C++ step */
-                    while (cnt - j >= 8) {
-                        unsigned da = lds_addr(dl + slot + j), za = lds_addr(zl + slot + j);
-                        unsigned long long fl;
-                        const unsigned want = __builtin_amdgcn_readfirstlane((unsigned)(cnt - j) / 8);   /* wave-uniform */
-                        const unsigned left = costas_asm_run(ph, fr, da, za, want, al, be, fmin_, fmax_, fl);
-                        j += 8 * (int)(want - left);
-                        if (left != 0) {
-                            for (int i = 0; i < 8; i++, j++) {
-                                float tx, ty; unsigned qq;
-                                costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
-                                zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
-                            }
-                        }
-                    }
-                }
-                float2 dcur = dl[slot + j];
-                if (fast_clamp) {
-#pragma unroll 1
-                    for (; j < cnt; j++) {
-                        const float2 dnext = dl[slot + j + 1];
-                        float tx, ty; unsigned qq;
-                        costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
-                        zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
-                        dcur = dnext;
-                    }
-                } else {
-#pragma unroll 4
-                    for (; j < cnt; j++) {
-                        const float2 dnext = dl[slot + j + 1];
-                        float tx, ty; unsigned qq;
-                        costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
-                        zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
-                        dcur = dnext;
-                    }
-                }
-            }
-            if (lane == 0) st_release(&sm->consumed, c + 1);
-        }
-        st.phase = ph; st.freq = fr;
-        if (active && ok) {
-            const size_t o = (size_t)(f0 + g) * nbw + b;
-            if (a.freq) a.freq[o] = st.freq;
-            if (a.phase) a.phase[o] = st.phase;
-            if (a.hz) a.hz[o] = (float)((double)st.freq * a.rs / TAU); /* qpsk.c:217 */
-            if (a.state_out) { a.state_out[2 * o] = st.phase; a.state_out[2 * o + 1] = st.freq; }
-        }
-        if (!ok && lane == 0) atomicExch(status, 1);
+        costas_wave(a, sm, dring, zring, G, f0, lane, nchunks, status);
         return;
     }
 
@@ -292,34 +412,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     bool ok = true;
 
     auto flush_upto = [&](int upto) {
-        /* symbols (and costas_frame) of chunks [flushed, upto) of this wave's frames: staging -> global */
-        for (; flushed < upto; flushed++) {
-            const int slot = (flushed % DR) * S, sym0 = flushed * S;
-            const int cnt = min(S, N - sym0);
-            if (!fvalid) continue;
-            for (int b = 0; b < nbw; b++) {
-                const int row = g * nbw + b;
-                const size_t o = ((size_t)frame * nbw + b) * N + sym0 + R * q;
-                float2 z[R];
-                uint32_t packed = 0;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const float4 tq = zring[(size_t)row * ZSTRIDE + slot + R * q + r];
-                    z[r] = apply_quadrant(tq.x, tq.y, __float_as_uint(tq.z));   /* qpsk.c:197 */
-                    packed |= (uint32_t)slicer(z[r]) << (8 * r);   /* qpsk_demod(), qpsk.c:74-79 */
-                }
-                if (R * q + R <= cnt && ((N | sym0) & 3) == 0) {
-                    *reinterpret_cast<uint32_t *>(a.sym + o) = packed;
-                } else {
-                    for (int r = 0; r < R; r++)
-                        if (R * q + r < cnt) a.sym[o + r] = (uint8_t)(packed >> (8 * r));
-                }
-                if (a.costas) {
-                    for (int r = 0; r < R; r++)
-                        if (R * q + r < cnt) a.costas[o + r] = z[r];
-                }
-            }
-        }
+        for (; flushed < upto; flushed++)
+            if (fvalid) flush_records(a, zring, g, frame, q, flushed);
     };
 
     for (int c = 0; c < nchunks; c++) {
@@ -416,8 +510,20 @@ int launch_rx_fused_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
     return (int)e;
 }
 
+int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
+{
+    const int G = NF * FWV;
+    const int blocks = (a.nframes + G - 1) / G;
+    const size_t lds = sizeof(Smem) + sizeof(float2) * (size_t)G * DSTRIDE + sizeof(float4) * (size_t)G * ZSTRIDE;
+    hipLaunchKernelGGL(costas_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1)), lds, s, a, status);
+    return (int)hipGetLastError();
+}
+
 int prepare_pipe_kernel(void)
 {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(costas_pipe_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
 }
