@@ -41,6 +41,7 @@ static int fail(int code, const char *fmt, ...)
 
 #define KERNEL_TRY(expr)                                                                      \
     do {                                                                                      \
+        (void)hipGetLastError(); /* a stale error of an unrelated earlier call must not be blamed on this launch */ \
         int e_ = (expr);                                                                      \
         if (e_ != 0)                                                                          \
             return fail(QPSK_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString((hipError_t)e_), __FILE__, __LINE__); \

@@ -416,30 +416,70 @@ decimate_kernel(const float2 *__restrict__ filtered, const int32_t *__restrict__
 
 /* ========================================================================
  * mixer_kernel: qpsk.c:114-120.  phase *= rect per sample is a serial complex
- * recurrence per stream: one lane per stream; the block is renormalised with
- * cabsf (glibc hypotf: exact squares in fp64, one rounded add, sqrt, narrow).
+ * recurrence per stream (a jump-ahead by rect^k would round differently), so
+ * one lane per stream, 16 streams per single-wave workgroup; PCM comes in and
+ * complex samples go out through LDS tiles of 64 samples so that every global
+ * access is a coalesced row (all 64 lanes on one stream's 64 samples).  The
+ * block ends with the renormalisation by cabsf (glibc hypotf: exact squares in
+ * fp64, one rounded add, correctly rounded sqrt, narrowed).
  * state: [nstreams][4] = phase.re, phase.im, rect.re, rect.im
  * ======================================================================== */
+constexpr int MX_STREAMS = 16;
+constexpr int MX_TILE = 64;
+
 __global__ void __launch_bounds__(64)
 mixer_kernel(const int16_t *__restrict__ pcm, float2 *__restrict__ out, float *state, int nstreams, int frame_size)
 {
-    const int f = blockIdx.x * 64 + threadIdx.x;
-    if (f >= nstreams) return;
+    __shared__ int16_t tin[MX_STREAMS][MX_TILE + 2];   /* rows 33 dwords apart: 16 lanes, 16 banks */
+    __shared__ float2 tout[MX_STREAMS][MX_TILE + 1];   /* rows 130 dwords apart */
+    const int lane = threadIdx.x, f0 = blockIdx.x * MX_STREAMS;
+    const bool scanning = lane < MX_STREAMS && f0 + lane < nstreams;
+    const int f = min(f0 + (lane & (MX_STREAMS - 1)), nstreams - 1);
     float pr = state[4 * f], pi = state[4 * f + 1];
     const float rr = state[4 * f + 2], ri = state[4 * f + 3];
-    const int16_t *in = pcm + (size_t)f * frame_size;
-    float2 *o = out + (size_t)f * frame_size;
-    for (int i = 0; i < frame_size; i++) {
-        const float nr = pr * rr - pi * ri;
-        const float ni = pr * ri + pi * rr;
-        pr = nr;
-        pi = ni;
-        const float v = (float)in[i] / 16384.0f;
-        o[i] = make_float2(pr * v, pi * v);
+    const int ntiles = (frame_size + MX_TILE - 1) / MX_TILE;
+
+    int16_t pre[MX_STREAMS];
+    auto fetch = [&](int t) {
+        const int s_ = min(t * MX_TILE + lane, frame_size - 1);
+#pragma unroll
+        for (int r = 0; r < MX_STREAMS; r++)
+            pre[r] = pcm[(size_t)min(f0 + r, nstreams - 1) * frame_size + s_];
+    };
+    fetch(0);
+    for (int t = 0; t < ntiles; t++) {
+#pragma unroll
+        for (int r = 0; r < MX_STREAMS; r++)
+            tin[r][lane] = pre[r];
+        if (t + 1 < ntiles) fetch(t + 1);
+        __syncthreads();
+        const int cnt = min(MX_TILE, frame_size - t * MX_TILE);
+        if (scanning) {
+            const int16_t *row = &tin[lane][0];
+            float2 *orow = &tout[lane][0];
+#pragma unroll 8
+            for (int i = 0; i < cnt; i++) {
+                const float nr = pr * rr - pi * ri;      /* fbb_rx_phase *= fbb_rx_rect, qpsk.c:115 */
+                const float ni = pr * ri + pi * rr;
+                pr = nr;
+                pi = ni;
+                const float v = (float)row[i] / 16384.0f;
+                orow[i] = make_float2(pr * v, pi * v);   /* qpsk.c:117 */
+            }
+        }
+        __syncthreads();
+        if (lane < cnt) {
+#pragma unroll
+            for (int r = 0; r < MX_STREAMS; r++)
+                if (f0 + r < nstreams)
+                    out[(size_t)(f0 + r) * frame_size + t * MX_TILE + lane] = tout[r][lane];
+        }
     }
-    const float mag = (float)sqrt((double)pr * (double)pr + (double)pi * (double)pi);
-    state[4 * f] = pr / mag;
-    state[4 * f + 1] = pi / mag;
+    if (scanning) {
+        const float mag = (float)sqrt((double)pr * (double)pr + (double)pi * (double)pi);   /* qpsk.c:120 */
+        state[4 * f] = pr / mag;
+        state[4 * f + 1] = pi / mag;
+    }
 }
 
 /* ========================================================================
@@ -575,7 +615,7 @@ int launch_decimate(const float *filtered, const int32_t *index, float *dec, int
 
 int launch_mixer(const int16_t *pcm, float *out, float *state, int nstreams, int frame_size, hipStream_t s)
 {
-    hipLaunchKernelGGL(mixer_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, s, pcm,
+    hipLaunchKernelGGL(mixer_kernel, dim3((nstreams + MX_STREAMS - 1) / MX_STREAMS), dim3(64), 0, s, pcm,
                        reinterpret_cast<float2 *>(out), state, nstreams, frame_size);
     LAUNCH_CHECK();
     return 0;

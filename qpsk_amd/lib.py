@@ -71,6 +71,13 @@ def load():
     if not os.path.exists(p):
         raise QpskError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(there is no CPU fallback)" % p)
+    # PyTorch ships its own libamdhip64; whichever HIP runtime is loaded first serves the whole process, and
+    # torch.cuda stops working if the system one got in before it.  This plumbing always shares the process with
+    # torch (device buffers are torch tensors), so let torch load its runtime first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(p)
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
     L.qpsk_last_error.restype = C.c_char_p
