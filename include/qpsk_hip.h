@@ -167,6 +167,25 @@ int qpsk_streams_rx_pcm(qpsk_ctx *ctx, const int16_t *d_pcm, uint8_t *d_sym, flo
                         float *d_costas, int32_t *d_index);
 
 /* -------------------------------------------------------------------------
+ * Bit-level stages after the slicer (algorithms/ of the reference, which its qpsk.c does
+ * not call yet), batched over independent packets.
+ * ------------------------------------------------------------------------- */
+
+/* crc16() (crc16.c:11-23: init 0xFFFF, polynomial 0x1021, no reflection, no final xor) of npackets packets of
+ * nbytes bytes each: d_data [npackets][nbytes] -> d_crc [npackets] uint16 */
+int qpsk_crc16_batch(qpsk_ctx *ctx, const uint8_t *d_data, int npackets, int nbytes, uint16_t *d_crc);
+
+/* interleave() (interleave.c:33-78), in place on each packet of nbytes bytes: bit i goes to bit (b*i) mod nbits,
+ * b = the largest table prime below nbits (the table ends at 347); dir 0 = INTERLEAVE, 1 = DEINTERLEAVE
+ * (interleave.h:10-11).  nbytes*8 must be < 65536 as in the reference (uint16_t nbits). */
+int qpsk_interleave_batch(qpsk_ctx *ctx, uint8_t *d_data, int npackets, int nbytes, int dir);
+
+/* scramble() (bit-scramble.c:57-84) on every 2-bit symbol of npackets frames of nsym symbols, in place, the
+ * 15-bit register reloaded with SEED 0x4A80 at the start of each frame (bit-scramble.c:11-13 "The Sync Seed is
+ * reset at the start of each frame"); additive, so scrambling twice restores the input. */
+int qpsk_scramble_batch(qpsk_ctx *ctx, uint8_t *d_sym, int npackets, int nsym);
+
+/* -------------------------------------------------------------------------
  * Small helpers so that a C host needs nothing but this library.
  * ------------------------------------------------------------------------- */
 int qpsk_dev_alloc(qpsk_ctx *ctx, void **d_ptr, size_t bytes);

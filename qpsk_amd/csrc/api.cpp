@@ -64,7 +64,8 @@ struct qpsk_ctx {
     float *d_gains = nullptr;    /* MAX_BW x (alpha, beta) */
     int *d_status = nullptr;     /* set by a kernel whose internal pipeline gave up (bounded spins) */
     std::vector<float> h_gains;
-    DevBuf index, filtered, mixed;
+    DevBuf index, filtered, mixed, keystream;
+    int keystream_len = 0;
     std::map<int, double *> twiddles;
     /* streams */
     int nstreams = 0;
@@ -215,6 +216,7 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
     hipFree(c->index.p);
     hipFree(c->filtered.p);
     hipFree(c->mixed.p);
+    hipFree(c->keystream.p);
     for (auto &kv : c->twiddles) hipFree(kv.second);
     free_streams(c);
     delete c;
@@ -638,6 +640,43 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
     /* qpsk.c:114-120 */
     KERNEL_TRY(launch_mixer(d_pcm, (float *)c->mixed.p, c->s_mixer, n, L, c->stream));
     return qpsk_streams_rx_cplx(c, (const float *)c->mixed.p, d_sym, d_freq, d_phase, d_costas, d_index);
+}
+
+/* ------------------------------------------------------------ bit stages */
+int qpsk_crc16_batch(qpsk_ctx *c, const uint8_t *d_data, int npackets, int nbytes, uint16_t *d_crc)
+{
+    if (!c || !d_data || !d_crc) return fail(QPSK_ERR_ARG, "qpsk_crc16_batch: null argument");
+    if (npackets <= 0 || nbytes < 0) return fail(QPSK_ERR_ARG, "npackets %d nbytes %d", npackets, nbytes);
+    if (bind(c)) return QPSK_ERR_HIP;
+    KERNEL_TRY(launch_crc16(d_data, npackets, nbytes, d_crc, c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_interleave_batch(qpsk_ctx *c, uint8_t *d_data, int npackets, int nbytes, int dir)
+{
+    if (!c || !d_data) return fail(QPSK_ERR_ARG, "qpsk_interleave_batch: null argument");
+    if (npackets <= 0 || nbytes <= 0 || nbytes * 8 >= 65536 || (dir != 0 && dir != 1))
+        return fail(QPSK_ERR_ARG, "npackets %d, nbytes %d (1..8191), dir %d (0|1)", npackets, nbytes, dir);
+    if (bind(c)) return QPSK_ERR_HIP;
+    KERNEL_TRY(launch_interleave(d_data, npackets, nbytes, qpsk_host_interleave_prime((unsigned)nbytes * 8u), dir, c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_scramble_batch(qpsk_ctx *c, uint8_t *d_sym, int npackets, int nsym)
+{
+    if (!c || !d_sym) return fail(QPSK_ERR_ARG, "qpsk_scramble_batch: null argument");
+    if (npackets <= 0 || nsym <= 0) return fail(QPSK_ERR_ARG, "npackets %d nsym %d", npackets, nsym);
+    if (bind(c)) return QPSK_ERR_HIP;
+    int rc = ensure(c, c->keystream, (size_t)nsym);
+    if (rc) return rc;
+    if (c->keystream_len != nsym) {
+        std::vector<unsigned char> ks((size_t)nsym);
+        qpsk_host_scramble_keystream(ks.data(), nsym);
+        HIP_TRY(hipMemcpy(c->keystream.p, ks.data(), (size_t)nsym, hipMemcpyHostToDevice));
+        c->keystream_len = nsym;
+    }
+    KERNEL_TRY(launch_scramble(d_sym, (const uint8_t *)c->keystream.p, npackets, nsym, c->stream));
+    return QPSK_OK;
 }
 
 /* ---------------------------------------------------------------- memory */

@@ -86,6 +86,36 @@ void qpsk_host_phases(int n, double *cs)
     }
 }
 
+/* the multiplier of the golden-prime interleaver: the largest table prime below nbits (interleave.c:15-23,40-45) */
+unsigned qpsk_host_interleave_prime(unsigned nbits)
+{
+    static const unsigned short primes[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67,
+        71, 73, 79, 83, 89, 97, 101, 103, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167, 173, 179, 181,
+        191, 193, 197, 199, 211, 223, 227, 229, 233, 239, 241, 251, 257, 263, 269, 271, 277, 281, 283, 293, 307, 311,
+        313, 317, 331, 337, 347};
+    const unsigned count = sizeof primes / sizeof primes[0];
+    unsigned k = 1;
+    while (k < count && primes[k] < nbits)
+        k++;
+    return primes[k - 1];
+}
+
+/* keystream of the DVB scrambler 1 + x^14 + x^15 from SEED 0x4A80, two bits per symbol (bit-scramble.c:11-69):
+ * ks[i] = (second output bit << 1) | first output bit of symbol i */
+void qpsk_host_scramble_keystream(unsigned char *ks, int nsym)
+{
+    unsigned short mem = 0x4A80;
+    for (int i = 0; i < nsym; i++) {
+        unsigned char k = 0;
+        for (int bit = 0; bit < 2; bit++) {
+            const unsigned short out = (unsigned short)(((mem & 0x2) >> 1) ^ (mem & 0x1));
+            k |= (unsigned char)(out << bit);
+            mem = (unsigned short)((mem >> 1) | (out << 14));
+        }
+        ks[i] = k;
+    }
+}
+
 void qpsk_host_twiddles(int n, double *tw)
 {
     for (int m = 0; m < n / 2; m++) {

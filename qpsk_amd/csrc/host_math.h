@@ -13,6 +13,8 @@ void qpsk_host_loop_gains(float damping, float loop_bw, float *alpha, float *bet
 void qpsk_host_rect(double hz, double fs, float rect[2]);
 void qpsk_host_twiddles(int n, double *tw); /* tw[n/2][2] = cos, sin of 2 pi m / n */
 void qpsk_host_phases(int n, double *cs);   /* cs[n][2]   = cos, sin of 2 pi i / n */
+unsigned qpsk_host_interleave_prime(unsigned nbits);
+void qpsk_host_scramble_keystream(unsigned char *ks, int nsym);
 
 #ifdef __cplusplus
 }

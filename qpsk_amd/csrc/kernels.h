@@ -63,6 +63,10 @@ int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, c
                       const double *cs, int32_t *index, hipStream_t s);
 int timing_fft_nfft(void);
 int timing_fft_first(void);
+/* bitstages.hip */
+int launch_crc16(const uint8_t *data, int npackets, int nbytes, uint16_t *crc, hipStream_t s);
+int launch_interleave(uint8_t *data, int npackets, int nbytes, unsigned b, int dir, hipStream_t s);
+int launch_scramble(uint8_t *sym, const uint8_t *keystream, int npackets, int nsym, hipStream_t s);
 int launch_fill_i32(int32_t *p, int n, int32_t v, hipStream_t s);
 int launch_sincos_hash(uint32_t first, uint32_t count, unsigned long long *acc, hipStream_t s);
 

@@ -48,7 +48,7 @@ API_SYMBOLS = [
     "qpsk_rx_batch_bw", "qpsk_rrc_fir_batch", "qpsk_timing_hist_batch", "qpsk_costas_batch", "qpsk_fft_batch",
     "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
     "qpsk_streams_rx_pcm", "qpsk_dev_alloc", "qpsk_dev_free", "qpsk_dev_upload", "qpsk_dev_download",
-    "qpsk_selftest_sincos_hash",
+    "qpsk_selftest_sincos_hash", "qpsk_crc16_batch", "qpsk_interleave_batch", "qpsk_scramble_batch",
 ]
 # every symbol include/qpsk_dropin.h declares
 DROPIN_SYMBOLS = [
@@ -106,6 +106,9 @@ def load():
     L.qpsk_streams_rx_cplx.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.qpsk_streams_rx_pcm.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.qpsk_selftest_sincos_hash.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong)]
+    L.qpsk_crc16_batch.argtypes = [vp, vp, i32, i32, vp]
+    L.qpsk_interleave_batch.argtypes = [vp, vp, i32, i32, i32]
+    L.qpsk_scramble_batch.argtypes = [vp, vp, i32, i32]
     _LIB = L
     return L
 
@@ -287,6 +290,25 @@ class Modem:
         a = (C.c_float * (2 * self.nstreams))()
         self._check(self.L.qpsk_streams_get_loop_state(self.h, a))
         return np.array(a, np.float32).reshape(-1, 2)
+
+    # ---- bit-level stages (algorithms/ of the reference)
+    def crc16(self, packets):
+        """packets: (P, nbytes) uint8 -> (P,) uint16 (torch int16 view returned as numpy uint16)"""
+        t = self.torch
+        d = self._dev(packets, t.uint8)
+        out = self.empty((d.shape[0],), t.int16)
+        self._check(self.L.qpsk_crc16_batch(self.h, _ptr(d), d.shape[0], d.shape[1], _ptr(out)))
+        return out.cpu().numpy().view(np.uint16)
+
+    def interleave(self, packets, direction):
+        d = self._dev(packets, self.torch.uint8).clone()
+        self._check(self.L.qpsk_interleave_batch(self.h, _ptr(d), d.shape[0], d.shape[1], int(direction)))
+        return d
+
+    def scramble(self, symbols):
+        d = self._dev(symbols, self.torch.uint8).clone()
+        self._check(self.L.qpsk_scramble_batch(self.h, _ptr(d), d.shape[0], d.shape[1]))
+        return d
 
     def sincos_hash(self, first, count):
         h = C.c_ulonglong()

@@ -327,6 +327,36 @@ def test_fft_batch(oracle):
     assert np.all(cpu(m.fft(np.eye(1, 512, dtype=np.complex128)))[0] == 2.0 ** -9)
 
 
+# ------------------------------------------------------------------ bit-level stages
+def test_bit_stages(oracle):
+    """crc16 / golden-prime interleaver / DVB scrambler, batched: against the oracle on random packets and against
+    the reference's recorded outputs (tests/golden/fft_bits.npz), incl. the only known answers the reference
+    carries: CRC("123456789") = 0x29B1 and the interleaver strings of interleave.c:100-102."""
+    m = modem()
+    g = golden("fft_bits.npz")
+    rng = np.random.default_rng(12)
+    for nbytes in (1, 2, 8, 22, 40, 43, 64, 255):
+        pk = rng.integers(0, 256, size=(37, nbytes)).astype(np.uint8)
+        crc = m.crc16(pk)
+        for p in range(pk.shape[0]):
+            assert int(crc[p]) == oracle.crc16(pk[p].tobytes())
+        fwd, back = cpu(m.interleave(pk, 0)), cpu(m.interleave(pk, 1))
+        for p in range(0, pk.shape[0], 9):
+            assert bits_equal(fwd[p], oracle.interleave(pk[p], 0)) and bits_equal(back[p], oracle.interleave(pk[p], 1))
+    assert int(m.crc16(np.frombuffer(b"123456789", np.uint8)[None].copy())[0]) == 0x29B1
+    assert bits_equal(cpu(m.interleave(g["il_in"][None], 0))[0], g["il_out"])
+    assert bits_equal(cpu(m.interleave(g["il_out"][None], 1))[0], g["il_back"])
+    assert bits_equal(cpu(m.interleave(g["il22_in"][None], 0))[0], g["il22_out"])
+    sc = cpu(m.scramble(np.repeat(g["scr_in"][None], 5, 0)))
+    for p in range(5):
+        assert bits_equal(sc[p], g["scr_out"])                          # register reloaded per frame
+    assert bits_equal(cpu(m.scramble(sc)), np.repeat(g["scr_in"][None], 5, 0))   # additive: twice = identity
+    syms = rng.integers(0, 4, size=(3, 2048)).astype(np.uint8)
+    sc2 = cpu(m.scramble(syms))
+    for p in range(3):
+        assert bits_equal(sc2[p], oracle.scramble_stream(syms[p]))
+
+
 # ------------------------------------------------------------------ the reference's own entry points (qpsk_dropin.h)
 def test_dropin_reference_signatures_golden():
     """rrc_make / create_control_loop / rx_frame / rrc_fir / fft exactly as the reference's main() calls them
