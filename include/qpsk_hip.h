@@ -167,6 +167,22 @@ int qpsk_streams_rx_pcm(qpsk_ctx *ctx, const int16_t *d_pcm, uint8_t *d_sym, flo
                         float *d_costas, int32_t *d_index);
 
 /* -------------------------------------------------------------------------
+ * TRANSMITTERS: nstreams independent modulators advancing
+ * one block per call with the reference's carried state -- the tx_filter
+ * delay line (rrc_fir.c:17, qpsk.c:243) and the carrier phase fbb_tx_phase
+ * (qpsk.c:45,249-253).  One call = one qpsk_packet_mod() (qpsk.c:273-285)
+ * per transmitter.
+ * ------------------------------------------------------------------------- */
+/* fbb_tx_phase = cmplx(0.0f); fbb_tx_rect = cmplx(TAU * tx_hz / FS); tx_filter zeroed (qpsk.c:316,320;
+ * the shipped main() uses tx_hz = CENTER + 50.0) */
+int qpsk_tx_reset(qpsk_ctx *ctx, int nstreams, double tx_hz);
+/* d_symbols [nstreams][nsym] uint8, the dibit (tx_bits[s] << 1) | tx_bits[s+1] of qpsk.c:277-281 (the value
+ * qpsk_rx_batch writes for the same symbol); d_pcm [nstreams][nsym*CYCLES] int16 as tx_frame() returns them
+ * (qpsk.c:259-261), may be NULL; d_baseband [nstreams][nsym*CYCLES][2] float, the shaped complex signal
+ * before the up-mix (qpsk.c:243), may be NULL -- not both */
+int qpsk_tx_symbols(qpsk_ctx *ctx, const uint8_t *d_symbols, int nsym, int16_t *d_pcm, float *d_baseband);
+
+/* -------------------------------------------------------------------------
  * Bit-level stages after the slicer (algorithms/ of the reference, which its qpsk.c does
  * not call yet), batched over independent packets.
  * ------------------------------------------------------------------------- */

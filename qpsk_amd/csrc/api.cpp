@@ -70,6 +70,10 @@ struct qpsk_ctx {
     /* streams */
     int nstreams = 0;
     float *s_memory = nullptr, *s_dec = nullptr, *s_loop = nullptr, *s_mixer = nullptr;
+    /* transmitters (N2) */
+    int ntx = 0;
+    float *t_memory = nullptr, *t_mixer = nullptr;
+    DevBuf tx_a, tx_b;
 };
 
 static const int MAX_BW = 64;
@@ -205,6 +209,14 @@ static void free_streams(qpsk_ctx *c)
     c->nstreams = 0;
 }
 
+static void free_transmitters(qpsk_ctx *c)
+{
+    hipFree(c->t_memory); hipFree(c->t_mixer); hipFree(c->tx_a.p); hipFree(c->tx_b.p);
+    c->t_memory = c->t_mixer = nullptr;
+    c->tx_a = DevBuf(); c->tx_b = DevBuf();
+    c->ntx = 0;
+}
+
 void qpsk_ctx_destroy(qpsk_ctx *c)
 {
     if (!c) return;
@@ -219,6 +231,7 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
     hipFree(c->keystream.p);
     for (auto &kv : c->twiddles) hipFree(kv.second);
     free_streams(c);
+    free_transmitters(c);
     delete c;
 }
 
@@ -640,6 +653,57 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
     /* qpsk.c:114-120 */
     KERNEL_TRY(launch_mixer(d_pcm, (float *)c->mixed.p, c->s_mixer, n, L, c->stream));
     return qpsk_streams_rx_cplx(c, (const float *)c->mixed.p, d_sym, d_freq, d_phase, d_costas, d_index);
+}
+
+/* ------------------------------------------------------------ transmit side (N2) */
+int qpsk_tx_reset(qpsk_ctx *c, int nstreams, double tx_hz)
+{
+    if (!c || nstreams <= 0) return fail(QPSK_ERR_ARG, "qpsk_tx_reset: bad argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)nstreams;
+    if (nstreams != c->ntx) {
+        hipFree(c->t_memory); hipFree(c->t_mixer);
+        c->t_memory = c->t_mixer = nullptr;
+        c->ntx = 0;
+        if (hipMalloc((void **)&c->t_memory, sizeof(float) * 2 * QPSK_NTAPS * n) != hipSuccess ||
+            hipMalloc((void **)&c->t_mixer, sizeof(float) * 4 * n) != hipSuccess)
+            return fail(QPSK_ERR_ALLOC, "hipMalloc of transmitter state failed");
+        c->ntx = nstreams;
+    }
+    HIP_TRY(hipMemsetAsync(c->t_memory, 0, sizeof(float) * 2 * QPSK_NTAPS * n, c->stream));
+    /* fbb_tx_phase = cmplx(0.0f); fbb_tx_rect = cmplx(TAU * hz / FS)  (qpsk.c:316,320) */
+    float rect[2];
+    qpsk_host_rect_tx(tx_hz, c->prm.fs, rect);
+    std::vector<float> m(4 * n);
+    for (size_t i = 0; i < n; i++) { m[4 * i] = 1.0f; m[4 * i + 1] = 0.0f; m[4 * i + 2] = rect[0]; m[4 * i + 3] = rect[1]; }
+    HIP_TRY(hipMemcpyAsync(c->t_mixer, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_tx_symbols(qpsk_ctx *c, const uint8_t *d_symbols, int nsym, int16_t *d_pcm, float *d_baseband)
+{
+    if (!c || !d_symbols || (!d_pcm && !d_baseband)) return fail(QPSK_ERR_ARG, "qpsk_tx_symbols: null argument");
+    if (c->ntx <= 0) return fail(QPSK_ERR_STATE, "call qpsk_tx_reset() first");
+    if (nsym <= 0) return fail(QPSK_ERR_ARG, "nsym = %d", nsym);
+    if (bind(c)) return QPSK_ERR_HIP;
+    const int n = c->ntx, len = nsym * c->cycles;
+    const size_t bytes = sizeof(float) * 2 * (size_t)n * len;
+    int rc = ensure(c, c->tx_a, bytes);
+    if (rc) return rc;
+    float *shaped = d_baseband;
+    if (!shaped) {
+        rc = ensure(c, c->tx_b, bytes);
+        if (rc) return rc;
+        shaped = (float *)c->tx_b.p;
+    }
+    /* qpsk.c:273-282 + 232-238: Gray map and zero-stuffing; :243 rrc_fir(tx_filter, ...); :248-261 up-mix */
+    KERNEL_TRY(launch_tx_map(d_symbols, (float *)c->tx_a.p, (size_t)n * len, c->cycles, c->stream));
+    KERNEL_TRY(launch_rrc_fir((const float *)c->tx_a.p, c->t_memory, shaped, c->d_taps, n, len, c->stream));
+    KERNEL_TRY(launch_delay_line((const float *)c->tx_a.p, c->t_memory, n, len, c->stream));
+    if (d_pcm) KERNEL_TRY(launch_tx_upmix(shaped, d_pcm, c->t_mixer, n, len, c->stream));
+    return QPSK_OK;
 }
 
 /* ------------------------------------------------------------ bit stages */

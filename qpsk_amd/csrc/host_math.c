@@ -76,6 +76,15 @@ void qpsk_host_rect(double hz, double fs, float rect[2])
     rect[1] = s * -1.0f;
 }
 
+/* transmit carrier step e^{+j 2 pi f/fs}: fbb_tx_rect = cmplx(TAU * hz / FS)  (qpsk.c:320, qpsk.h:35) */
+void qpsk_host_rect_tx(double hz, double fs, float rect[2])
+{
+    const float a = (float)(2.0 * PI_D * hz / fs);
+    const float s = sinf(a);
+    rect[0] = cosf(a) + s * 0.0f; /* cosf(v) + sinf(v) * I */
+    rect[1] = s * 1.0f;
+}
+
 /* (cos, sin)(2 pi i / n) for i < n: the candidate timing phases of the FFT timing estimate (timing_fft.hip) */
 void qpsk_host_phases(int n, double *cs)
 {

@@ -11,6 +11,7 @@ extern "C" {
 void qpsk_host_rrc_taps(float fs, float rs, float alpha, float taps[QPSK_HOST_NTAPS]);
 void qpsk_host_loop_gains(float damping, float loop_bw, float *alpha, float *beta);
 void qpsk_host_rect(double hz, double fs, float rect[2]);
+void qpsk_host_rect_tx(double hz, double fs, float rect[2]);
 void qpsk_host_twiddles(int n, double *tw); /* tw[n/2][2] = cos, sin of 2 pi m / n */
 void qpsk_host_phases(int n, double *cs);   /* cs[n][2]   = cos, sin of 2 pi i / n */
 unsigned qpsk_host_interleave_prime(unsigned nbits);

@@ -49,6 +49,7 @@ API_SYMBOLS = [
     "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
     "qpsk_streams_rx_pcm", "qpsk_dev_alloc", "qpsk_dev_free", "qpsk_dev_upload", "qpsk_dev_download",
     "qpsk_selftest_sincos_hash", "qpsk_crc16_batch", "qpsk_interleave_batch", "qpsk_scramble_batch",
+    "qpsk_tx_reset", "qpsk_tx_symbols",
 ]
 # every symbol include/qpsk_dropin.h declares
 DROPIN_SYMBOLS = [
@@ -109,6 +110,8 @@ def load():
     L.qpsk_crc16_batch.argtypes = [vp, vp, i32, i32, vp]
     L.qpsk_interleave_batch.argtypes = [vp, vp, i32, i32, i32]
     L.qpsk_scramble_batch.argtypes = [vp, vp, i32, i32]
+    L.qpsk_tx_reset.argtypes = [vp, i32, C.c_double]
+    L.qpsk_tx_symbols.argtypes = [vp, vp, i32, vp, vp]
     _LIB = L
     return L
 
@@ -292,6 +295,23 @@ class Modem:
         return np.array(a, np.float32).reshape(-1, 2)
 
     # ---- bit-level stages (algorithms/ of the reference)
+    # ---- transmitters (qpsk.c:225-285)
+    def tx_reset(self, nstreams, tx_hz=1550.0):
+        self._check(self.L.qpsk_tx_reset(self.h, nstreams, tx_hz))
+        self.ntx = nstreams
+
+    def tx_symbols(self, symbols, want_pcm=True, want_baseband=False):
+        """symbols: (ntx, nsym) uint8 dibits -> dict(pcm (ntx, nsym*CYCLES) int16, baseband (ntx, nsym*CYCLES, 2))"""
+        t = self.torch
+        d = self._dev(symbols, t.uint8)
+        if d.dim() != 2 or d.shape[0] != getattr(self, "ntx", 0):
+            raise ValueError("symbols must be (ntx, nsym) after tx_reset(ntx)")
+        n = d.shape[1] * self.cycles
+        pcm = self.empty((d.shape[0], n), t.int16) if want_pcm else None
+        bb = self.empty((d.shape[0], n, 2), t.float32) if want_baseband else None
+        self._check(self.L.qpsk_tx_symbols(self.h, _ptr(d), d.shape[1], _ptr(pcm), _ptr(bb)))
+        return dict(pcm=pcm, baseband=bb)
+
     def crc16(self, packets):
         """packets: (P, nbytes) uint8 -> (P,) uint16 (torch int16 view returned as numpy uint16)"""
         t = self.torch

@@ -402,6 +402,52 @@ def test_dropin_reference_signatures_golden():
     L.qpsk_dropin_shutdown()
 
 
+# ------------------------------------------------------------------ transmitters (qpsk.c:225-285)
+def dibits(bits):
+    """tx_bits[] -> the symbol value qpsk_packet_mod() looks up: (tx_bits[s] << 1) | tx_bits[s+1] (qpsk.c:277-281)"""
+    bits = np.asarray(bits, np.uint8)
+    return ((bits[..., 0::2] << 1) | bits[..., 1::2]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name", ["shipped", "c1small"])
+def test_tx_golden(name):
+    g = golden("tx_%s.npz" % name)
+    fs, rs = float(g["fs"]), float(g["rs"])
+    m = modem(fs=fs, rs=rs, frame_size=int(fs / rs) * 64)
+    m.tx_reset(3, float(g["tx_hz"]))
+    for bits, pcm, bb in zip(g["bits"], g["pcm"], g["baseband"]):
+        o = m.tx_symbols(np.repeat(dibits(bits)[None], 3, 0), want_pcm=True, want_baseband=True)
+        m.sync()
+        for s in range(3):
+            assert np.array_equal(cpu(o["pcm"][s]), pcm)
+            assert bits_equal(cpu(o["baseband"][s]), bb)
+
+
+@pytest.mark.parametrize("fs,rs,S", [(19200.0, 2400.0, 37), (9600.0, 2400.0, 16), (9600.0, 1200.0, 5)])
+def test_tx_vs_oracle_many_transmitters(oracle, fs, rs, S):
+    """every transmitter has its own symbols, block lengths are ragged (1 symbol .. several tiles), state carried"""
+    cycles = int(fs / rs)
+    m = modem(fs=fs, rs=rs, frame_size=cycles * 64)
+    m.tx_reset(S, 1550.0)
+    otx = [oracle.tx(fs, rs, np.float32(.35), 1550.0) for _ in range(S)]
+    rng = np.random.default_rng(41)
+    for nsym in (1, 7, 64, 129, 1000, 3):
+        bits = rng.integers(0, 2, size=(S, 2 * nsym)).astype(np.int32)
+        o = m.tx_symbols(dibits(bits))
+        m.sync()
+        got = cpu(o["pcm"])
+        for s in range(S):
+            assert np.array_equal(got[s], otx[s].symbols(bits[s])), (nsym, s)
+    with pytest.raises(Exception):
+        m.tx_symbols(np.zeros((S + 1, 4), np.uint8))
+
+
+def test_tx_requires_reset():
+    m = modem(fs=9600.0, rs=2400.0, frame_size=512)
+    with pytest.raises(Exception):
+        m.tx_symbols(np.zeros((1, 4), np.uint8))
+
+
 # ------------------------------------------------------------------ streams (consecutive rx_frame calls)
 @pytest.mark.parametrize("name", ["shipped", "c1small"])
 def test_streams_pcm_golden(name):

@@ -121,6 +121,15 @@ def test_bit_stages(oracle):
     assert bits_equal(oracle.scramble_stream(g["scr_in"]), g["scr_out"])
 
 
+@pytest.mark.parametrize("name", ["shipped", "c1small"])
+def test_transmitter(oracle, name):
+    """qpsk_packet_mod() -> tx_frame() (qpsk.c:225-285) over consecutive blocks, state carried"""
+    g = golden("tx_%s.npz" % name)
+    tx = oracle.tx(float(g["fs"]), float(g["rs"]), np.float32(.35), float(g["tx_hz"]))
+    for bits, pcm in zip(g["bits"], g["pcm"]):
+        assert np.array_equal(tx.symbols(bits.astype(np.int32)), pcm)
+
+
 def test_slicer_and_detector(oracle):
     g = golden("fft_bits.npz")
     for (a, b), d, e in zip(g["pts"], g["demod"], g["detector"]):

@@ -137,6 +137,20 @@ def gen_fir():
                         **{"m%d" % i: v for i, v in enumerate(rec["mem"])})
 
 
+def gen_tx(name, nblocks, nsym, seed):
+    """The reference's transmitter (qpsk_packet_mod -> tx_frame, qpsk.c:225-285) over consecutive blocks with
+    its carried state (tx_filter, fbb_tx_phase); the shaped baseband of the same bits from a second run."""
+    ref = Reference(name)
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, size=(nblocks, 2 * nsym)).astype(np.int32)
+    ref.reset(LOOP_BW, -1.0, 1.0, .35, 1550.0, 1500.0)
+    pcm = np.stack([ref.tx_symbols(b) for b in bits])
+    ref.reset(LOOP_BW, -1.0, 1.0, .35, 1550.0, 1500.0)
+    bb = np.stack([ref.tx_baseband(b) for b in bits])
+    np.savez_compressed(os.path.join(OUT, "tx_%s.npz" % name), fs=ref.fs, rs=ref.rs, tx_hz=1550.0, bits=bits.astype(np.uint8),
+                        pcm=pcm, baseband=bb)
+
+
 def gen_fft_bits():
     ref = Reference("shipped")
     rng = np.random.default_rng(9)
@@ -172,15 +186,28 @@ def gen_fft_bits():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_taps()
-    gen_fir()
-    gen_stream_pcm("shipped", 8, 11)
-    gen_stream_pcm("c1small", 6, 12)
-    gen_stream_cplx("c1small", 6, 13)
-    gen_stream_cplx("c5small", 3, 14)
-    gen_independent("c1small", 8, 21)
-    gen_independent("c1", 2, 22)
-    gen_independent("c5small", 3, 23, loop_bw=np.float32(TAU / 200.0), tag="_bw200")
-    gen_fft_bits()
+    only = set(sys.argv[1:])   # e.g. "tx" regenerates the transmitter fixtures alone; no argument = everything
+
+    def want(group):
+        return not only or group in only
+
+    if want("taps"):
+        gen_taps()
+    if want("fir"):
+        gen_fir()
+    if want("stream"):
+        gen_stream_pcm("shipped", 8, 11)
+        gen_stream_pcm("c1small", 6, 12)
+        gen_stream_cplx("c1small", 6, 13)
+        gen_stream_cplx("c5small", 3, 14)
+    if want("independent"):
+        gen_independent("c1small", 8, 21)
+        gen_independent("c1", 2, 22)
+        gen_independent("c5small", 3, 23, loop_bw=np.float32(TAU / 200.0), tag="_bw200")
+    if want("fft_bits"):
+        gen_fft_bits()
+    if want("tx"):
+        gen_tx("shipped", 6, 100, 31)
+        gen_tx("c1small", 4, 333, 32)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, "total bytes", tot)
