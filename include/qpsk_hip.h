@@ -134,8 +134,9 @@ int qpsk_rx_batch_bw(qpsk_ctx *ctx, const float *d_in, int nframes, const float 
  *   fits the library's staging (it copies first); prefer separate buffers. */
 int qpsk_rrc_fir_batch(qpsk_ctx *ctx, float *d_memory, const float *d_in, float *d_out, int nframes, int length);
 
-/* timing histogram (qpsk.c:127-180) of nframes filtered blocks -> d_index[nframes] */
-int qpsk_timing_hist_batch(qpsk_ctx *ctx, const float *d_filtered, int nframes, int32_t *d_index);
+/* timing histogram (qpsk.c:127-180) of nframes filtered blocks -> d_index[nframes]; d_hist, if not NULL,
+ * receives hist_i[k] + hist_q[k], k = 0..7 (qpsk.c:175, locals of rx_frame) as [nframes][8] */
+int qpsk_timing_hist_batch(qpsk_ctx *ctx, const float *d_filtered, int nframes, int32_t *d_index, int32_t *d_hist);
 
 /* Costas loop + slicer (qpsk.c:196-212) over already decimated symbols.
  *   d_symbols_in [nframes][nsym] complex float;  d_state [nframes][2] float (phase, freq) in/out,

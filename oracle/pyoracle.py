@@ -66,6 +66,7 @@ class Oracle:
                                      C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.qo_demod.argtypes = [C.c_float, C.c_float]
         L.qo_timing_index.argtypes = [_f32p, C.c_int, C.c_int]
+        L.qo_timing_hist.argtypes = [_f32p, C.c_int, C.c_int, _i32p]
         L.qo_timing_fft_index.argtypes = [_f32p, _f32p, C.c_int, C.c_int]
         L.qo_modem_new.argtypes = [C.c_double, C.c_double, C.c_int, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_int, C.c_int]
@@ -105,6 +106,12 @@ class Oracle:
 
     def timing_index(self, filtered, cycles):
         return self.lib.qo_timing_index(filtered.reshape(-1), filtered.size // 2, cycles)
+
+    def timing_hist(self, filtered, cycles):
+        """-> (index, hist_i + hist_q as int32[8])"""
+        h = np.zeros(8, np.int32)
+        idx = self.lib.qo_timing_hist(filtered.reshape(-1), filtered.size // 2, cycles, h)
+        return idx, h
 
     def timing_fft_index(self, taps, frame, cycles):
         return self.lib.qo_timing_fft_index(np.ascontiguousarray(taps, np.float32), np.ascontiguousarray(frame, np.float32).reshape(-1),

@@ -206,6 +206,13 @@ int qo_costas_step(qo_costas *c, float d_re, float d_im, float *z_re, float *z_i
 
 int qo_timing_index(const float *x, int frame_size, int cycles)
 {
+    int hist[8];
+    return qo_timing_hist(x, frame_size, cycles, hist);
+}
+
+/* the same, also handing out hist_i[k] + hist_q[k] (qpsk.c:175), which the reference only keeps in locals */
+int qo_timing_hist(const float *x, int frame_size, int cycles, int hist[8])
+{
     float max_i = 0.0f, max_q = 0.0f, av_i = 0.0f, av_q = 0.0f;
     int hist_i[8] = {0}, hist_q[8] = {0};
 
@@ -227,6 +234,7 @@ int qo_timing_index(const float *x, int frame_size, int cycles)
     int hmax = 0, index = 0;
     for (int k = 0; k < 8; k++) {
         const int h = hist_i[k] + hist_q[k];
+        hist[k] = h;
         if (h > hmax) { hmax = h; index = k; }
     }
     return index;

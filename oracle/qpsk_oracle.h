@@ -62,6 +62,7 @@ int qo_demod(float re, float im);                                               
 
 /* ---- timing histogram (qpsk.c:90-108,127-180) on one filtered block ---- */
 int qo_timing_index(const float *filtered, int frame_size, int cycles);
+int qo_timing_hist(const float *filtered, int frame_size, int cycles, int hist[8]); /* + hist_i[k]+hist_q[k], qpsk.c:175 */
 
 /* ---- FFT timing estimate: NOT in the reference (parity unpinned by it); definition in
  * qpsk_amd/csrc/timing_fft.hip, restated here for the parity tests. x = one fresh frame BEFORE the FIR ---- */

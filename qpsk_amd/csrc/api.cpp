@@ -373,7 +373,7 @@ static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int
         if (rc) return rc;
         KERNEL_TRY(launch_rrc_fir(d_in, nullptr, (float *)c->filtered.p, c->d_taps, nframes, c->prm.frame_size, c->stream));
         KERNEL_TRY(launch_timing_hist((const float *)c->filtered.p, nframes, c->prm.frame_size, c->cycles,
-                                      (int32_t *)c->index.p, c->stream));
+                                      (int32_t *)c->index.p, nullptr, c->stream));
         *d_index_out = (const int32_t *)c->index.p;
         return QPSK_OK;
     }
@@ -521,12 +521,12 @@ int qpsk_rrc_fir_batch(qpsk_ctx *c, float *d_memory, const float *d_in, float *d
     return QPSK_OK;
 }
 
-int qpsk_timing_hist_batch(qpsk_ctx *c, const float *d_filtered, int nframes, int32_t *d_index)
+int qpsk_timing_hist_batch(qpsk_ctx *c, const float *d_filtered, int nframes, int32_t *d_index, int32_t *d_hist)
 {
     if (!c || !d_filtered || !d_index) return fail(QPSK_ERR_ARG, "qpsk_timing_hist_batch: null argument");
     if (nframes <= 0) return fail(QPSK_ERR_ARG, "nframes = %d", nframes);
     if (bind(c)) return QPSK_ERR_HIP;
-    KERNEL_TRY(launch_timing_hist(d_filtered, nframes, c->prm.frame_size, c->cycles, d_index, c->stream));
+    KERNEL_TRY(launch_timing_hist(d_filtered, nframes, c->prm.frame_size, c->cycles, d_index, d_hist, c->stream));
     return QPSK_OK;
 }
 
@@ -624,7 +624,7 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
     KERNEL_TRY(launch_delay_line(d_in, c->s_memory, n, L, c->stream));
     /* qpsk.c:127-180 */
     if (c->prm.timing_mode == QPSK_TIMING_HIST)
-        KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, c->stream));
+        KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, nullptr, c->stream));
     else if (c->prm.timing_mode == QPSK_TIMING_FIXED)
         KERNEL_TRY(launch_fill_i32(idx, n, c->prm.fixed_index, c->stream));
     else

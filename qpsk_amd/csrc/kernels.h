@@ -49,7 +49,8 @@ int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s);
 int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s);
-int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, hipStream_t s);
+int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, int32_t *hist,
+                       hipStream_t s);
 int launch_costas(const float *d, int nframes, int nsym, int dstride, int nbw, const float *gains, float min_freq,
                   float max_freq, const float *state_in, float *state_out, uint8_t *sym, float *costas,
                   hipStream_t s);

@@ -282,7 +282,8 @@ constexpr int TH_FRAMES = 16;
 constexpr int TH_TILE = 64;
 
 __global__ void __launch_bounds__(64)
-timing_hist_kernel(const float *__restrict__ y, int nframes, int frame_size, int cycles, int32_t *index)
+timing_hist_kernel(const float *__restrict__ y, int nframes, int frame_size, int cycles, int32_t *index,
+                   int32_t *hist_out)
 {
     __shared__ float2 tile[TH_FRAMES][TH_TILE + 1];
     const int lane = threadIdx.x;
@@ -366,9 +367,99 @@ timing_hist_kernel(const float *__restrict__ y, int nframes, int frame_size, int
     for (int q = 0; q < 8; q++) {
         const int h = hist[q] + __shfl_xor(hist[q], 1);
         if (h > hmax) { hmax = h; best = q; }
+        if (hist_out && scanning && comp == 0) hist_out[(size_t)(f0 + fl) * 8 + q] = h;
     }
     if (scanning && comp == 0)
         index[f0 + fl] = best;
+}
+
+/* ========================================================================
+ * timing_hist8_kernel: the same scan for CYCLES = 8 and frames of whole
+ * 128-sample tiles, with the scan wave stripped to the recurrence.
+ *
+ * The scan is latency-bound (one serial chain per frame and component: the
+ * running average is 8 dependent adds and a multiply per symbol), so what
+ * counts is the instruction stream of the scanning wave (a lone wave issues
+ * one VALU op per ~5 cycles, a dependent one after ~8, an LDS op per ~12):
+ *   - the 7 threshold compares of a symbol (qpsk.c:147-165) do not depend on
+ *     each other, so they go ACROSS lanes instead of down the instruction
+ *     stream: 8 lanes per (frame, component), lane q owns threshold hv*q.
+ *     Every lane of the group runs the same average/max chain on the same
+ *     samples (LDS broadcast reads) and adds one compare + one count;
+ *   - hv*q is nondecreasing in q, so "the first q with av <= hv*q" is
+ *     1 + #{q : !(av <= hv*q)}: lane q counts cum[q] = #{symbols : !(av <= hv*q)}
+ *     and hist[q] = cum[q-1] - cum[q], cum[0] = number of symbols (a NaN
+ *     average is counted by every lane and lands in no bin, as in the
+ *     reference's compare chain);
+ *   - a wave scans 4 frames and stages its own tiles: 16-byte global loads
+ *     prefetched a tile ahead, I and Q de-interleaved into two LDS planes so
+ *     that a symbol's 8 samples of one component are two ds_read_b128;
+ *   - av / 8 is av * 0.125f (both correctly rounded of the same real number).
+ * ======================================================================== */
+constexpr int TH8_FRAMES = 4;
+constexpr int TH8_TILE = 128;
+constexpr int TH8_PITCH = TH8_TILE + 4;      /* floats; rows 16-byte aligned, 4 banks apart */
+
+__global__ void __launch_bounds__(64)
+timing_hist8_kernel(const float *__restrict__ y, int nframes, int frame_size, int32_t *index, int32_t *hist_out)
+{
+    __shared__ __attribute__((aligned(16))) float tile[2][TH8_FRAMES][TH8_PITCH];   /* [I|Q][frame][sample] */
+    const int lane = threadIdx.x;
+    const int f0 = blockIdx.x * TH8_FRAMES;
+    const int ntiles = frame_size / TH8_TILE;
+
+    /* staging: lane l carries samples 2l, 2l+1 of every frame's tile */
+    const float4 *y4 = reinterpret_cast<const float4 *>(y);
+    float4 pre[TH8_FRAMES];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < TH8_FRAMES; r++)
+            pre[r] = y4[((size_t)min(f0 + r, nframes - 1) * frame_size + (size_t)t * TH8_TILE) / 2 + lane];
+    };
+
+    /* scanning: lane = 16*frame + 8*component + q */
+    const int fl = lane >> 4, comp = (lane >> 3) & 1, q = lane & 7;
+    const float qf = (float)q;
+    const float4 *row = reinterpret_cast<const float4 *>(&tile[comp][fl][0]);
+    float av = 0.0f, mx = 0.0f;
+    int cum = 0;
+
+    fetch(0);
+    for (int t = 0; t < ntiles; t++) {
+        __syncthreads();          /* the scan of tile t-1 is over */
+#pragma unroll
+        for (int r = 0; r < TH8_FRAMES; r++) {
+            *reinterpret_cast<float2 *>(&tile[0][r][2 * lane]) = make_float2(pre[r].x, pre[r].z);
+            *reinterpret_cast<float2 *>(&tile[1][r][2 * lane]) = make_float2(pre[r].y, pre[r].w);
+        }
+        if (t + 1 < ntiles) fetch(t + 1);
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < TH8_TILE / 8; s++) {
+            const float4 a = row[2 * s], b = row[2 * s + 1];
+            av += fabsf(a.x); av += fabsf(a.y); av += fabsf(a.z); av += fabsf(a.w);
+            av += fabsf(b.x); av += fabsf(b.y); av += fabsf(b.z); av += fabsf(b.w);
+            av *= 0.125f;                           /* av /= CYCLES */
+            if (av > mx) mx = av;
+            const float th = (mx * 0.125f) * qf;    /* (max / 8.0f) * q */
+            cum += (av <= th) ? 0 : 1;
+        }
+    }
+    /* lane q = 0 stands for cum[0] = the number of symbols */
+    if (q == 0) cum = frame_size / 8;
+    int h = __shfl_up(cum, 1) - cum;           /* hist[q], q >= 1 */
+    if (q == 0) h = 0;
+    h += __shfl_xor(h, 8);                     /* hist_i + hist_q (qpsk.c:175) */
+    int hmax = 0, best = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int hk = __shfl(h, (lane & ~7) + k);
+        if (hk > hmax) { hmax = hk; best = k; }
+    }
+    if (f0 + fl < nframes && comp == 0) {
+        if (hist_out) hist_out[(size_t)(f0 + fl) * 8 + q] = h;
+        if (q == 0) index[f0 + fl] = best;
+    }
 }
 
 /* ========================================================================
@@ -583,10 +674,18 @@ int launch_delay_line(const float *x, float *memory, int nframes, int length, hi
     return 0;
 }
 
-int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, hipStream_t s)
+int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, int32_t *hist,
+                       hipStream_t s)
 {
+    const bool generic = getenv("QPSK_HIST_GENERIC") != nullptr;   /* test knob: always the generic scan */
+    if (cycles == 8 && frame_size % TH8_TILE == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && !generic) {
+        hipLaunchKernelGGL(timing_hist8_kernel, dim3((nframes + TH8_FRAMES - 1) / TH8_FRAMES), dim3(64), 0, s, y,
+                           nframes, frame_size, index, hist);
+        LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(timing_hist_kernel, dim3((nframes + TH_FRAMES - 1) / TH_FRAMES), dim3(64), 0, s, y, nframes,
-                       frame_size, cycles, index);
+                       frame_size, cycles, index, hist);
     LAUNCH_CHECK();
     return 0;
 }

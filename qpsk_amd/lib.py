@@ -98,7 +98,7 @@ def load():
     L.qpsk_rx_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.qpsk_rx_batch_bw.argtypes = [vp, vp, i32, C.POINTER(f32), i32, vp, vp, vp, vp]
     L.qpsk_rrc_fir_batch.argtypes = [vp, vp, vp, vp, i32, i32]
-    L.qpsk_timing_hist_batch.argtypes = [vp, vp, i32, vp]
+    L.qpsk_timing_hist_batch.argtypes = [vp, vp, i32, vp, vp]
     L.qpsk_costas_batch.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.qpsk_fft_batch.argtypes = [vp, vp, vp, i32, i32, i32]
     L.qpsk_streams_reset.argtypes = [vp, i32, C.c_double]
@@ -238,12 +238,13 @@ class Modem:
         self._check(self.L.qpsk_rrc_fir_batch(self.h, _ptr(memory), _ptr(x), _ptr(y), x.shape[0], x.shape[1]))
         return y
 
-    def timing_hist(self, filtered):
+    def timing_hist(self, filtered, want_hist=False):
         t = self.torch
         y = self._dev(filtered, t.float32)
         idx = self.empty((y.shape[0],), t.int32)
-        self._check(self.L.qpsk_timing_hist_batch(self.h, _ptr(y), y.shape[0], _ptr(idx)))
-        return idx
+        hist = self.empty((y.shape[0], 8), t.int32) if want_hist else None
+        self._check(self.L.qpsk_timing_hist_batch(self.h, _ptr(y), y.shape[0], _ptr(idx), _ptr(hist)))
+        return (idx, hist) if want_hist else idx
 
     def costas(self, d, state=None, want_costas=True):
         t = self.torch

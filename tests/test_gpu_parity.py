@@ -273,16 +273,27 @@ def test_fir_golden():
         assert bits_equal(cpu(y[0]), g["y%d" % i]) and bits_equal(cpu(d_mem[0]), g["m%d" % i])
 
 
-@pytest.mark.parametrize("cycles,L", [(8, 1024), (4, 512), (5, 1000), (8, 16384)])
-def test_timing_histogram(oracle, cycles, L):
+@pytest.mark.parametrize("cycles,L,generic", [(8, 1024, 0), (8, 1024, 1), (4, 512, 0), (5, 1000, 0), (8, 16384, 0),
+                                               (8, 16384, 1), (8, 1032, 0), (8, 128, 0)])
+def test_timing_histogram(oracle, monkeypatch, cycles, L, generic):
+    """index AND the summed histograms hist_i + hist_q (qpsk.c:175) for both scans (the CYCLES = 8 kernel and the
+    generic one, which also takes the frames that are not whole 128-sample tiles)"""
+    if generic:
+        monkeypatch.setenv("QPSK_HIST_GENERIC", "1")
     rs = 2400.0
     m = modem(fs=rs * cycles, rs=rs, frame_size=L)
-    x, _ = make_frames(30, L, cycles, m.taps, rs * cycles, noise=0.1, base_seed=cycles)
+    x, _ = make_frames(37, L, cycles, m.taps, rs * cycles, noise=0.1, base_seed=cycles)
     x[0] = 0.0
     x[1] = random_frames(1, L, seed=5)[0]
-    idx = cpu(m.timing_hist(x))
+    x[2] = np.abs(random_frames(1, L, seed=6)[0]) * np.linspace(0.01, 3.0, L)[:, None]     # the running max keeps moving
+    x[3, L // 2:] = 0.0
+    x[4] *= 1e-30                                                                            # averages near the denormals
+    idx, hist = m.timing_hist(x, want_hist=True)
+    idx, hist = cpu(idx), cpu(hist)
     for f in range(x.shape[0]):
-        assert idx[f] == oracle.timing_index(x[f], cycles), f
+        want_idx, want_hist = oracle.timing_hist(x[f], cycles)
+        assert np.array_equal(hist[f], want_hist), (f, hist[f], want_hist)
+        assert idx[f] == want_idx, f
 
 
 def test_costas_batch_with_state(oracle):
