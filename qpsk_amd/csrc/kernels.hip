@@ -516,56 +516,91 @@ decimate_kernel(const float2 *__restrict__ filtered, const int32_t *__restrict__
  * state: [nstreams][4] = phase.re, phase.im, rect.re, rect.im
  * ======================================================================== */
 constexpr int MX_STREAMS = 16;
-constexpr int MX_TILE = 64;
+constexpr int MX_TILE = 128;
 
 __global__ void __launch_bounds__(64)
 mixer_kernel(const int16_t *__restrict__ pcm, float2 *__restrict__ out, float *state, int nstreams, int frame_size)
 {
-    __shared__ int16_t tin[MX_STREAMS][MX_TILE + 2];   /* rows 33 dwords apart: 16 lanes, 16 banks */
-    __shared__ float2 tout[MX_STREAMS][MX_TILE + 1];   /* rows 130 dwords apart */
+    /* Two passes per tile of 128 samples.  Serial pass: lanes 0..15 run ONLY the carrier recurrence of their
+     * stream and leave the tile's phases in LDS (3 packed VALU ops per sample, two phases per 16-byte store).
+     * Parallel pass: all 64 lanes take one stream's row at a time -- a lane owns two neighbouring samples --
+     * scale the PCM pair (one 4-byte load, prefetched a tile ahead), multiply by the phases and store 16 bytes:
+     * coalesced rows straight from registers, no transposes. */
+    __shared__ __attribute__((aligned(16))) float2 ph[MX_STREAMS][MX_TILE + 2];   /* rows 260 dwords apart */
     const int lane = threadIdx.x, f0 = blockIdx.x * MX_STREAMS;
     const bool scanning = lane < MX_STREAMS && f0 + lane < nstreams;
     const int f = min(f0 + (lane & (MX_STREAMS - 1)), nstreams - 1);
-    float pr = state[4 * f], pi = state[4 * f + 1];
+    float2 p = make_float2(state[4 * f], state[4 * f + 1]);
     const float rr = state[4 * f + 2], ri = state[4 * f + 3];
     const int ntiles = (frame_size + MX_TILE - 1) / MX_TILE;
 
-    int16_t pre[MX_STREAMS];
-    auto fetch = [&](int t) {
-        const int s_ = min(t * MX_TILE + lane, frame_size - 1);
+    /* the paired accesses need whole rows of streams, an even frame size and aligned bases (wave-uniform) */
+    const bool fast = f0 + MX_STREAMS <= nstreams && (frame_size & 1) == 0 &&
+                      (reinterpret_cast<uintptr_t>(pcm) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    uint32_t pre[MX_STREAMS];
+    auto fetch = [&](int t) {                            /* full tiles on the fast path only */
 #pragma unroll
-        for (int r = 0; r < MX_STREAMS; r++)
-            pre[r] = pcm[(size_t)min(f0 + r, nstreams - 1) * frame_size + s_];
+        for (int r = 0; r < MX_STREAMS; r++) {
+            const int16_t *rowp = pcm + (size_t)(f0 + r) * frame_size + (size_t)t * MX_TILE;   /* uniform base */
+            pre[r] = reinterpret_cast<const uint32_t *>(rowp)[lane];
+        }
     };
-    fetch(0);
+    float nri = -ri;
+    asm volatile("" : "+v"(nri));   /* opaque: keeps the compiler from folding the sign back into two packed adds */
+    auto step = [&]() {                                  /* fbb_rx_phase *= fbb_rx_rect, qpsk.c:115 */
+        const float2 a = make_float2(p.x * rr, p.y * rr);
+        const float2 b = make_float2(p.y * nri, p.x * ri);   /* p.y * (-ri) = -(p.y * ri) exactly: re = a.x - p.y*ri */
+        p = make_float2(a.x + b.x, a.y + b.y);
+    };
+    if (fast && frame_size >= MX_TILE) fetch(0);
     for (int t = 0; t < ntiles; t++) {
-#pragma unroll
-        for (int r = 0; r < MX_STREAMS; r++)
-            tin[r][lane] = pre[r];
-        if (t + 1 < ntiles) fetch(t + 1);
-        __syncthreads();
         const int cnt = min(MX_TILE, frame_size - t * MX_TILE);
+        __syncthreads();                                  /* the parallel pass of tile t-1 has read ph[] */
         if (scanning) {
-            const int16_t *row = &tin[lane][0];
-            float2 *orow = &tout[lane][0];
+            float4 *prow = reinterpret_cast<float4 *>(&ph[lane][0]);
+            if (cnt == MX_TILE) {
 #pragma unroll 8
-            for (int i = 0; i < cnt; i++) {
-                const float nr = pr * rr - pi * ri;      /* fbb_rx_phase *= fbb_rx_rect, qpsk.c:115 */
-                const float ni = pr * ri + pi * rr;
-                pr = nr;
-                pi = ni;
-                const float v = (float)row[i] / 16384.0f;
-                orow[i] = make_float2(pr * v, pi * v);   /* qpsk.c:117 */
+                for (int i = 0; i < MX_TILE / 2; i++) {
+                    step();
+                    const float2 p0 = p;
+                    step();
+                    prow[i] = make_float4(p0.x, p0.y, p.x, p.y);
+                }
+            } else {
+                for (int i = 0; i < cnt; i++) {
+                    step();
+                    ph[lane][i] = p;
+                }
             }
         }
         __syncthreads();
-        if (lane < cnt) {
+        if (fast && cnt == MX_TILE) {                    /* wave-uniform: no per-row branches, uniform row bases */
+            float4 c[MX_STREAMS];
 #pragma unroll
             for (int r = 0; r < MX_STREAMS; r++)
-                if (f0 + r < nstreams)
-                    out[(size_t)(f0 + r) * frame_size + t * MX_TILE + lane] = tout[r][lane];
+                c[r] = *reinterpret_cast<const float4 *>(&ph[r][2 * lane]);
+#pragma unroll
+            for (int r = 0; r < MX_STREAMS; r++) {
+                float2 *orow = out + (size_t)(f0 + r) * frame_size + (size_t)t * MX_TILE;
+                const float v0 = (float)(int16_t)(pre[r] & 0xffffu) / 16384.0f;
+                const float v1 = (float)(int16_t)(pre[r] >> 16) / 16384.0f;
+                reinterpret_cast<float4 *>(orow)[lane] =
+                    make_float4(c[r].x * v0, c[r].y * v0, c[r].z * v1, c[r].w * v1);   /* qpsk.c:117 */
+            }
+            if ((t + 2) * MX_TILE <= frame_size) fetch(t + 1);
+        } else {
+            for (int i = lane; i < cnt; i += 64) {
+#pragma unroll 1
+                for (int r = 0; r < MX_STREAMS && f0 + r < nstreams; r++) {
+                    const size_t at = (size_t)(f0 + r) * frame_size + (size_t)t * MX_TILE + i;
+                    const float v = (float)pcm[at] / 16384.0f;
+                    const float2 c = ph[r][i];
+                    out[at] = make_float2(c.x * v, c.y * v);
+                }
+            }
         }
     }
+    const float pr = p.x, pi = p.y;
     if (scanning) {
         const float mag = (float)sqrt((double)pr * (double)pr + (double)pi * (double)pi);   /* qpsk.c:120 */
         state[4 * f] = pr / mag;

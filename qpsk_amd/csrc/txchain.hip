@@ -29,54 +29,87 @@ tx_map_kernel(const uint8_t *__restrict__ sym, float2 *__restrict__ sig, size_t 
  * carrier phase is renormalised.  Serial per transmitter like mixer_kernel: 16 transmitters per single-wave
  * workgroup, LDS tiles for coalesced rows.  state: [n][4] = phase.re, phase.im, rect.re, rect.im */
 constexpr int TXM_STREAMS = 16;
-constexpr int TXM_TILE = 64;
+constexpr int TXM_TILE = 128;
 
 __global__ void __launch_bounds__(64)
 tx_upmix_kernel(const float2 *__restrict__ sig, int16_t *__restrict__ pcm, float *state, int nstreams, int length)
 {
-    __shared__ float2 tin[TXM_STREAMS][TXM_TILE + 1];
-    __shared__ int16_t tout[TXM_STREAMS][TXM_TILE + 2];
+    /* two passes per tile, as in mixer_kernel: lanes 0..15 run only the carrier recurrence and leave the tile's 64
+     * phases in LDS; then all 64 lanes take one transmitter's row at a time (lane = sample) */
+    __shared__ __attribute__((aligned(16))) float2 ph[TXM_STREAMS][TXM_TILE + 2];
     const int lane = threadIdx.x, f0 = blockIdx.x * TXM_STREAMS;
     const bool scanning = lane < TXM_STREAMS && f0 + lane < nstreams;
     const int f = min(f0 + (lane & (TXM_STREAMS - 1)), nstreams - 1);
-    float pr = state[4 * f], pi = state[4 * f + 1];
+    float2 p = make_float2(state[4 * f], state[4 * f + 1]);
     const float rr = state[4 * f + 2], ri = state[4 * f + 3];
-    const int ntiles = (length + TXM_TILE - 1) / TXM_TILE;
-    float2 pre[TXM_STREAMS];
-    auto fetch = [&](int t) {
-        const int s_ = min(t * TXM_TILE + lane, length - 1);
-#pragma unroll
-        for (int r = 0; r < TXM_STREAMS; r++)
-            pre[r] = sig[(size_t)min(f0 + r, nstreams - 1) * length + s_];
+    float nri = -ri;
+    asm volatile("" : "+v"(nri));   /* opaque, see mixer_kernel */
+    auto step = [&]() {              /* fbb_tx_phase *= fbb_tx_rect, qpsk.c:249 */
+        const float2 a = make_float2(p.x * rr, p.y * rr);
+        const float2 b = make_float2(p.y * nri, p.x * ri);
+        p = make_float2(a.x + b.x, a.y + b.y);
     };
-    fetch(0);
-    for (int t = 0; t < ntiles; t++) {
+    const int ntiles = (length + TXM_TILE - 1) / TXM_TILE;
+    /* the paired accesses need whole rows of transmitters, an even length and aligned bases (wave-uniform) */
+    const bool fast = f0 + TXM_STREAMS <= nstreams && (length & 1) == 0 &&
+                      (reinterpret_cast<uintptr_t>(sig) & 15) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 3) == 0;
+    float4 pre[TXM_STREAMS];
+    auto fetch = [&](int t) {                               /* full tiles on the fast path only */
 #pragma unroll
-        for (int r = 0; r < TXM_STREAMS; r++)
-            tin[r][lane] = pre[r];
-        if (t + 1 < ntiles) fetch(t + 1);
-        __syncthreads();
+        for (int r = 0; r < TXM_STREAMS; r++) {
+            const float2 *rowp = sig + (size_t)(f0 + r) * length + (size_t)t * TXM_TILE;   /* uniform base */
+            pre[r] = reinterpret_cast<const float4 *>(rowp)[lane];
+        }
+    };
+    if (fast && length >= TXM_TILE) fetch(0);
+    for (int t = 0; t < ntiles; t++) {
         const int cnt = min(TXM_TILE, length - t * TXM_TILE);
+        __syncthreads();
         if (scanning) {
+            float4 *prow = reinterpret_cast<float4 *>(&ph[lane][0]);
+            if (cnt == TXM_TILE) {
 #pragma unroll 8
-            for (int i = 0; i < cnt; i++) {
-                const float nr = pr * rr - pi * ri;
-                const float ni = pr * ri + pi * rr;
-                pr = nr;
-                pi = ni;
-                const float2 s = tin[lane][i];
-                const float re = s.x * pr - s.y * pi;       /* real part of signal[i] * phase; the imaginary part is discarded */
-                tout[lane][i] = (int16_t)(re * 16384.0f);   /* C conversion: truncation toward zero (in range for this modem) */
+                for (int i = 0; i < TXM_TILE / 2; i++) {
+                    step();
+                    const float2 p0 = p;
+                    step();
+                    prow[i] = make_float4(p0.x, p0.y, p.x, p.y);
+                }
+            } else {
+                for (int i = 0; i < cnt; i++) {
+                    step();
+                    ph[lane][i] = p;
+                }
             }
         }
         __syncthreads();
-        if (lane < cnt) {
+        if (fast && cnt == TXM_TILE) {                      /* wave-uniform: no per-row branches, uniform row bases */
+            float4 c[TXM_STREAMS];
 #pragma unroll
             for (int r = 0; r < TXM_STREAMS; r++)
-                if (f0 + r < nstreams)
-                    pcm[(size_t)(f0 + r) * length + t * TXM_TILE + lane] = tout[r][lane];
+                c[r] = *reinterpret_cast<const float4 *>(&ph[r][2 * lane]);
+#pragma unroll
+            for (int r = 0; r < TXM_STREAMS; r++) {
+                int16_t *orow = pcm + (size_t)(f0 + r) * length + (size_t)t * TXM_TILE;
+                const float4 s = pre[r];
+                /* real part of signal[i] * phase; the imaginary part is discarded; C conversion: toward zero */
+                const int16_t lo = (int16_t)((s.x * c[r].x - s.y * c[r].y) * 16384.0f);
+                const int16_t hi = (int16_t)((s.z * c[r].z - s.w * c[r].w) * 16384.0f);
+                reinterpret_cast<uint32_t *>(orow)[lane] = (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16);
+            }
+            if ((t + 2) * TXM_TILE <= length) fetch(t + 1);
+        } else {
+            for (int i = lane; i < cnt; i += 64) {
+#pragma unroll 1
+                for (int r = 0; r < TXM_STREAMS && f0 + r < nstreams; r++) {
+                    const size_t at = (size_t)(f0 + r) * length + (size_t)t * TXM_TILE + i;
+                    const float2 c = ph[r][i], s = sig[at];
+                    pcm[at] = (int16_t)((s.x * c.x - s.y * c.y) * 16384.0f);
+                }
+            }
         }
     }
+    const float pr = p.x, pi = p.y;
     if (scanning) {
         const float mag = (float)sqrt((double)pr * (double)pr + (double)pi * (double)pi);   /* qpsk.c:253 */
         state[4 * f] = pr / mag;

@@ -39,6 +39,19 @@ def main():
         t = float(np.median(ts[1:]))
         print("streams %s (%s timing): %d x %d samples per block: %.3f ms -> %.0f Msamples/s" % (
             name, args.timing, n, bench.L, t, n * bench.L / t / 1e3))
+    # transmit side: the same number of transmitters, one block of nsym symbols each (qpsk.c:273-285)
+    m.tx_reset(n, 1550.0)
+    sym = torch.randint(0, 4, (n, m.nsym), dtype=torch.uint8, device=dev)
+    ts = []
+    for b in range(args.blocks):
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        m.tx_symbols(sym)
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(e))
+    t = float(np.median(ts[1:]))
+    print("transmitters: %d x %d samples per block: %.3f ms -> %.0f Msamples/s" % (n, bench.L, t, n * bench.L / t / 1e3))
 
 
 if __name__ == "__main__":
