@@ -54,6 +54,7 @@ struct DevBuf {
 
 struct qpsk_ctx {
     int device = 0;
+    int ncu = 256;                /* compute units of the device (256 on MI355X) */
     hipStream_t stream = nullptr; /* caller's stream; nullptr = default stream */
     qpsk_params prm{};
     int cycles = 0, nsym = 0;
@@ -180,6 +181,11 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
     KERNEL_TRY(prepare_pipe_kernel());
     qpsk_ctx *c = new qpsk_ctx();
     c->device = device;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
+            c->ncu = ncu;
+    }
     c->prm = *p;
     c->cycles = cycles;
     c->nsym = p->frame_size / cycles;
@@ -418,16 +424,26 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
     /* the pipeline kernel (rx_fused.hip) is built for CYCLES = 8, 16-byte aligned frames and an index
      * below CYCLES; everything else takes the generic chunked kernel (kernels.hip) */
     const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 &&
-                         ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames_per_wave() <= 64 &&
+                         ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames_per_wave(false) <= 64 &&
                          !env_int("QPSK_FUSED_GENERIC", 0);
     if (pipe_ok) {
-        int nf = (nframes + 256 * pipe_frames_per_wave() - 1) / (256 * pipe_frames_per_wave());
-        if (nf > pipe_max_nf()) nf = pipe_max_nf();
+        /* geometry: a batch that leaves at most 16 frames to a CU is bounded by the recurrence and takes the
+         * narrow workgroups (16 frames, serial wave alone on its SIMD); a bigger one is bounded by the FIR
+         * waves and takes the wide ones (32 frames, two FIR waves per SIMD) -- see rx_fused.hip */
+        bool wide = nframes > c->ncu * pipe_max_nf(false) * pipe_frames_per_wave(false) &&
+                    pipe_max_nf(true) * pipe_frames_per_wave(true) * nbw <= 64;
+        wide = env_int("QPSK_PIPE_WIDE", wide ? 1 : 0) != 0;
+        const int full = pipe_max_nf(wide);
+        const int fwv = pipe_frames_per_wave(wide);
+        int nf = wide ? full : (nframes + c->ncu * fwv - 1) / (c->ncu * fwv);
+        if (nf > full) nf = full;
         nf = env_int("QPSK_PIPE_NF", nf);
         if (nf < 1) nf = 1;
-        if (nf > pipe_max_nf()) nf = pipe_max_nf();
-        while (nf > 1 && nf * pipe_frames_per_wave() * nbw > 64) nf--;
-        KERNEL_TRY(launch_rx_fused_pipe(a, nf, c->d_status, c->stream));
+        if (nf > full) nf = full;
+        while (nf > 1 && nf * fwv * nbw > 64) nf--;
+        if (nf * fwv * nbw > 64 || pipe_lds_bytes(nf, nbw, wide) > (size_t)MAX_LDS_BYTES)
+            return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame, wide %d", nf, nbw, (int)wide);
+        KERNEL_TRY(launch_rx_fused_pipe(a, nf, wide, c->d_status, c->stream));
     } else {
         KERNEL_TRY(launch_rx_fused(a, c->stream));
     }
@@ -494,9 +510,9 @@ static int costas_over_symbols(qpsk_ctx *c, const float *d_symbols, int nframes,
     a.dsrc = reinterpret_cast<const float2 *>(d_symbols);
     a.dstride = dstride;
     a.dbg = env_int("QPSK_PIPE_DBG", 0);
-    int nf = (nframes + 256 * pipe_frames_per_wave() - 1) / (256 * pipe_frames_per_wave());
+    int nf = (nframes + c->ncu * pipe_frames_per_wave(false) - 1) / (c->ncu * pipe_frames_per_wave(false));
     if (nf < 1) nf = 1;
-    if (nf > pipe_max_nf()) nf = pipe_max_nf();
+    if (nf > pipe_max_nf(false)) nf = pipe_max_nf(false);
     KERNEL_TRY(launch_costas_pipe(a, nf, c->d_status, c->stream));
     return QPSK_OK;
 }

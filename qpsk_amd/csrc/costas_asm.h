@@ -28,12 +28,13 @@
  *     min(|T.x|, |T.y|) == 0   (the detector's sgn(0) = -1 asymmetry, see costas_step_t)
  *     a phase still outside [-2pi, 2pi] after ONE wrap (clamp wider than +-2pi, huge amplitudes).
  *
- * Registers: v[200:235] are scratch owned by the block (clobbered):
- *   200:201 x / d*C      202:203 beta*e, alpha*e   204:205 n / x3 / d*S     206:207 xr / e
- *   208:209 x2 / a, b    210:211 cos chain (v210 = C)   212:213 sin chain (v212 = S)
- *   214:217 the record: T.x, T.y, then the magic sum (v216 bits 1:0 = quadrant, v217 don't care)
- *   218 f2   219 p+f2    220:223 two decimated symbols   226 running min   227 2pi hi   228:229 +-2pi
- *   230,231 group-start phase/freq    232..235 phase/freq ping-pong
+ * Registers: v[100:135] are scratch owned by the block (clobbered; low enough for a kernel built for three
+ * waves per SIMD, i.e. at most 168 VGPRs):
+ *   100:101 x / d*C      102:103 beta*e, alpha*e   104:105 n / x3 / d*S     106:107 xr / e
+ *   108:109 x2 / a, b    110:111 cos chain (v110 = C)   112:113 sin chain (v112 = S)
+ *   114:117 the record: T.x, T.y, then the magic sum (v116 bits 1:0 = quadrant, v117 don't care)
+ *   118 f2   119 p+f2    120:123 two decimated symbols   126 running min   127 2pi hi   128:129 +-2pi
+ *   130,131 group-start phase/freq    132..135 phase/freq ping-pong
  */
 #ifndef QPSK_COSTAS_ASM_H
 #define QPSK_COSTAS_ASM_H
@@ -57,56 +58,56 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
  * of this step's record, LW/LR = the out-of-line wrap block's label and its return label.
  */
 #define QPSK_COSTAS_STEP(PIN, FIN, POUT, FOUT, DREG, WAIT, READ, ZOFF, LW, LR)                                \
-    "v_cvt_f64_f32 v[200:201], " PIN "\n\t"                                                                   \
-    "v_fma_f64 v[216:217], v[200:201], %[k2pi], %[magic]\n\t"                                                 \
-    "v_add_f64 v[204:205], v[216:217], -%[magic]\n\t"                                                         \
-    "v_fma_f64 v[206:207], -v[204:205], %[hpi], v[200:201]\n\t"                                               \
-    "v_mul_f64 v[208:209], v[206:207], v[206:207]\n\t"                                                        \
-    "v_fma_f64 v[210:211], v[208:209], %[c4], %[c3]\n\t"                                                      \
-    "v_fma_f64 v[212:213], v[208:209], %[s3], %[s2]\n\t"                                                      \
-    "v_fma_f64 v[210:211], v[208:209], v[210:211], %[c2]\n\t"                                                 \
-    "v_mul_f64 v[204:205], v[206:207], v[208:209]\n\t"                                                        \
-    "v_fma_f64 v[210:211], v[208:209], v[210:211], %[c1]\n\t"                                                 \
-    "v_fma_f64 v[212:213], v[208:209], v[212:213], %[s1]\n\t"                                                 \
-    "v_fma_f64 v[210:211], v[208:209], v[210:211], 1.0\n\t"                                                   \
-    "v_fma_f64 v[212:213], v[204:205], v[212:213], v[206:207]\n\t"                                            \
-    "v_cvt_f32_f64 v210, v[210:211]\n\t"                                                                      \
-    "v_cvt_f32_f64 v212, v[212:213]\n\t"                                                                      \
+    "v_cvt_f64_f32 v[100:101], " PIN "\n\t"                                                                   \
+    "v_fma_f64 v[116:117], v[100:101], %[k2pi], %[magic]\n\t"                                                 \
+    "v_add_f64 v[104:105], v[116:117], -%[magic]\n\t"                                                         \
+    "v_fma_f64 v[106:107], -v[104:105], %[hpi], v[100:101]\n\t"                                               \
+    "v_mul_f64 v[108:109], v[106:107], v[106:107]\n\t"                                                        \
+    "v_fma_f64 v[110:111], v[108:109], %[c4], %[c3]\n\t"                                                      \
+    "v_fma_f64 v[112:113], v[108:109], %[s3], %[s2]\n\t"                                                      \
+    "v_fma_f64 v[110:111], v[108:109], v[110:111], %[c2]\n\t"                                                 \
+    "v_mul_f64 v[104:105], v[106:107], v[108:109]\n\t"                                                        \
+    "v_fma_f64 v[110:111], v[108:109], v[110:111], %[c1]\n\t"                                                 \
+    "v_fma_f64 v[112:113], v[108:109], v[112:113], %[s1]\n\t"                                                 \
+    "v_fma_f64 v[110:111], v[108:109], v[110:111], 1.0\n\t"                                                   \
+    "v_fma_f64 v[112:113], v[104:105], v[112:113], v[106:107]\n\t"                                            \
+    "v_cvt_f32_f64 v110, v[110:111]\n\t"                                                                      \
+    "v_cvt_f32_f64 v112, v[112:113]\n\t"                                                                      \
     WAIT                                                                                                      \
-    "v_pk_mul_f32 v[200:201], " DREG ", v[210:211] op_sel_hi:[1,0]\n\t"                                       \
-    "v_pk_mul_f32 v[204:205], " DREG ", v[212:213] op_sel:[1,0] op_sel_hi:[0,0]\n\t"                          \
+    "v_pk_mul_f32 v[100:101], " DREG ", v[110:111] op_sel_hi:[1,0]\n\t"                                       \
+    "v_pk_mul_f32 v[104:105], " DREG ", v[112:113] op_sel:[1,0] op_sel_hi:[0,0]\n\t"                          \
     READ                                                                                                      \
-    "v_pk_add_f32 v[214:215], v[200:201], v[204:205] neg_hi:[0,1]\n\t"                                        \
-    "v_cmp_lt_f32_e32 vcc, 0, v214\n\t"                                                                       \
-    "v_cmp_lt_f32_e64 %[tm], 0, v215\n\t"                                                                     \
-    "v_min3_f32 v226, v226, |v214|, |v215|\n\t"                                                               \
-    "v_cndmask_b32_e64 v208, -v215, v215, vcc\n\t"                                                            \
-    "v_cndmask_b32_e64 v209, -v214, v214, %[tm]\n\t"                                                          \
-    "v_sub_f32_e32 v206, v208, v209\n\t"                                                                      \
-    "v_pk_mul_f32 v[202:203], %[beal], v[206:207] op_sel_hi:[1,0]\n\t"                                        \
-    "v_add_f32_e32 v218, " FIN ", v202\n\t"                                                                   \
-    "v_add_f32_e32 v219, " PIN ", v218\n\t"                                                                   \
-    "v_add_f32_e32 " POUT ", v219, v203\n\t"                                                                  \
+    "v_pk_add_f32 v[114:115], v[100:101], v[104:105] neg_hi:[0,1]\n\t"                                        \
+    "v_cmp_lt_f32_e32 vcc, 0, v114\n\t"                                                                       \
+    "v_cmp_lt_f32_e64 %[tm], 0, v115\n\t"                                                                     \
+    "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
+    "v_cndmask_b32_e64 v108, -v115, v115, vcc\n\t"                                                            \
+    "v_cndmask_b32_e64 v109, -v114, v114, %[tm]\n\t"                                                          \
+    "v_sub_f32_e32 v106, v108, v109\n\t"                                                                      \
+    "v_pk_mul_f32 v[102:103], %[beal], v[106:107] op_sel_hi:[1,0]\n\t"                                        \
+    "v_add_f32_e32 v118, " FIN ", v102\n\t"                                                                   \
+    "v_add_f32_e32 v119, " PIN ", v118\n\t"                                                                   \
+    "v_add_f32_e32 " POUT ", v119, v103\n\t"                                                                  \
     "v_cmp_ge_f32_e64 vcc, |" POUT "|, %[tau]\n\t"                                                            \
-    "ds_write_b128 %[za], v[214:217] offset:" QPSK_STR(ZOFF) "\n\t"                                           \
-    "v_med3_f32 " FOUT ", v218, %[fmin], %[fmax]\n\t"                                                         \
+    "ds_write_b128 %[za], v[114:117] offset:" QPSK_STR(ZOFF) "\n\t"                                           \
+    "v_med3_f32 " FOUT ", v118, %[fmin], %[fmax]\n\t"                                                         \
     "s_cbranch_vccnz " LW "f\n"                                                                               \
     LR ":\n\t"
 
 /* the out-of-line wrap of costas_loop.c:61-67 for one step: phase -= copysign(2pi, phase) in fp64, once */
 #define QPSK_COSTAS_WRAP(POUT, LW, LR)                                                                        \
     LW ":\n\t"                                                                                                \
-    "v_cvt_f64_f32 v[200:201], " POUT "\n\t"                                                                  \
-    "v_bfi_b32 v229, %[absm], v227, " POUT "\n\t"                                                             \
-    "v_add_f64 v[200:201], v[200:201], -v[228:229]\n\t"                                                       \
-    "v_cvt_f32_f64 v204, v[200:201]\n\t"                                                                      \
-    "v_cndmask_b32_e32 " POUT ", " POUT ", v204, vcc\n\t"                                                     \
+    "v_cvt_f64_f32 v[100:101], " POUT "\n\t"                                                                  \
+    "v_bfi_b32 v129, %[absm], v127, " POUT "\n\t"                                                             \
+    "v_add_f64 v[100:101], v[100:101], -v[128:129]\n\t"                                                       \
+    "v_cvt_f32_f64 v104, v[100:101]\n\t"                                                                      \
+    "v_cndmask_b32_e32 " POUT ", " POUT ", v104, vcc\n\t"                                                     \
     "v_cmp_ge_f32_e64 vcc, |" POUT "|, %[tau]\n\t"                                                            \
     "s_or_b64 %[fl], %[fl], vcc\n\t"                                                                          \
     "s_branch " LR "b\n"
 
 #define QPSK_WAIT1 "s_waitcnt lgkmcnt(1)\n\t"
-#define QPSK_RD(OFF) "ds_read_b128 v[220:223], %[da] offset:" QPSK_STR(OFF) "\n\t"
+#define QPSK_RD(OFF) "ds_read_b128 v[120:123], %[da] offset:" QPSK_STR(OFF) "\n\t"
 
 /*
  * Runs up to `groups` groups of 8 steps starting at LDS addresses d_addr (symbols, 8 bytes each, 16-byte
@@ -126,24 +127,24 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         __builtin_memcpy(&beal, &ba, 8);
     }
     asm volatile(
-        "v_mov_b32 v228, 0x54442d18\n\t"        /* 2*pi = 0x401921FB54442D18 */
-        "v_mov_b32 v227, 0x401921fb\n\t"
-        "ds_read_b128 v[220:223], %[da]\n\t"
+        "v_mov_b32 v128, 0x54442d18\n\t"        /* 2*pi = 0x401921FB54442D18 */
+        "v_mov_b32 v127, 0x401921fb\n\t"
+        "ds_read_b128 v[120:123], %[da]\n\t"
         "s_mov_b64 %[fl], 0\n\t"
         "s_waitcnt lgkmcnt(0)\n"
         "2:\n\t"
-        "v_mov_b32 v230, %[p]\n\t"
-        "v_mov_b32 v231, %[f]\n\t"
-        "v_mov_b32 v226, 0x7f800000\n\t"        /* running min of |T.x|, |T.y| over the group: 0 <=> some exact zero */
-        QPSK_COSTAS_STEP("%[p]", "%[f]", "v232", "v233", "v[220:221]", QPSK_WAIT1, "", 0, "10", "20")
-        QPSK_COSTAS_STEP("v232", "v233", "v234", "v235", "v[222:223]", "", QPSK_RD(16), 16, "11", "21")
-        QPSK_COSTAS_STEP("v234", "v235", "v232", "v233", "v[220:221]", QPSK_WAIT1, "", 32, "12", "22")
-        QPSK_COSTAS_STEP("v232", "v233", "v234", "v235", "v[222:223]", "", QPSK_RD(32), 48, "13", "23")
-        QPSK_COSTAS_STEP("v234", "v235", "v232", "v233", "v[220:221]", QPSK_WAIT1, "", 64, "14", "24")
-        QPSK_COSTAS_STEP("v232", "v233", "v234", "v235", "v[222:223]", "", QPSK_RD(48), 80, "15", "25")
-        QPSK_COSTAS_STEP("v234", "v235", "v232", "v233", "v[220:221]", QPSK_WAIT1, "", 96, "16", "26")
-        QPSK_COSTAS_STEP("v232", "v233", "%[p]", "%[f]", "v[222:223]", "", QPSK_RD(64), 112, "17", "27")
-        "v_cmp_eq_f32_e64 %[tm], 0, v226\n\t"
+        "v_mov_b32 v130, %[p]\n\t"
+        "v_mov_b32 v131, %[f]\n\t"
+        "v_mov_b32 v126, 0x7f800000\n\t"        /* running min of |T.x|, |T.y| over the group: 0 <=> some exact zero */
+        QPSK_COSTAS_STEP("%[p]", "%[f]", "v132", "v133", "v[120:121]", QPSK_WAIT1, "", 0, "10", "20")
+        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", QPSK_RD(16), 16, "11", "21")
+        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[120:121]", QPSK_WAIT1, "", 32, "12", "22")
+        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", QPSK_RD(32), 48, "13", "23")
+        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[120:121]", QPSK_WAIT1, "", 64, "14", "24")
+        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", QPSK_RD(48), 80, "15", "25")
+        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[120:121]", QPSK_WAIT1, "", 96, "16", "26")
+        QPSK_COSTAS_STEP("v132", "v133", "%[p]", "%[f]", "v[122:123]", "", QPSK_RD(64), 112, "17", "27")
+        "v_cmp_eq_f32_e64 %[tm], 0, v126\n\t"
         "s_or_b64 %[fl], %[fl], %[tm]\n\t"
         "s_cmp_lg_u64 %[fl], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
@@ -154,16 +155,16 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         "s_cbranch_scc1 2b\n\t"
         "s_branch 4f\n"
         "3:\n\t"
-        "v_mov_b32 %[p], v230\n\t"
-        "v_mov_b32 %[f], v231\n\t"
+        "v_mov_b32 %[p], v130\n\t"
+        "v_mov_b32 %[f], v131\n\t"
         "s_branch 4f\n"
-        QPSK_COSTAS_WRAP("v232", "10", "20")
-        QPSK_COSTAS_WRAP("v234", "11", "21")
-        QPSK_COSTAS_WRAP("v232", "12", "22")
-        QPSK_COSTAS_WRAP("v234", "13", "23")
-        QPSK_COSTAS_WRAP("v232", "14", "24")
-        QPSK_COSTAS_WRAP("v234", "15", "25")
-        QPSK_COSTAS_WRAP("v232", "16", "26")
+        QPSK_COSTAS_WRAP("v132", "10", "20")
+        QPSK_COSTAS_WRAP("v134", "11", "21")
+        QPSK_COSTAS_WRAP("v132", "12", "22")
+        QPSK_COSTAS_WRAP("v134", "13", "23")
+        QPSK_COSTAS_WRAP("v132", "14", "24")
+        QPSK_COSTAS_WRAP("v134", "15", "25")
+        QPSK_COSTAS_WRAP("v132", "16", "26")
         QPSK_COSTAS_WRAP("%[p]", "17", "27")
         "4:\n\t"
         "s_waitcnt lgkmcnt(0)"
@@ -173,9 +174,9 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
           [k2pi] "s"(0x1.45F306DC9C883p-1), [hpi] "s"(0x1.921FB54442D18p0), [c4] "s"(0x1.99343027bf8c3p-16),
           [s3] "s"(-0x1.994eb3774cf24p-13), [c2] "s"(0x1.55553e1068f19p-5), [s1] "s"(-0x1.555545995a603p-3),
           [c1] "s"(-0x1.ffffffd0c621cp-2), [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu)
-        : "vcc", "scc", "memory", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209",
-          "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222",
-          "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235");
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+          "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
+          "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135");
     flags_out = flags;
     return groups;
 }

@@ -39,12 +39,12 @@ size_t fused_lds_bytes(int G, int S, int cycles, int nbw);
 int prepare_kernels(void);
 int launch_rx_fused(const FusedArgs &a, hipStream_t s);
 /* rx_fused.hip: the producer/consumer pipeline kernel (CYCLES = 8 only) */
-size_t pipe_lds_bytes(int NF, int nbw, bool want_costas);
-int pipe_frames_per_wave(void);
+size_t pipe_lds_bytes(int NF, int nbw, bool wide);
+int pipe_frames_per_wave(bool wide);   /* 4 in both geometries */
 int pipe_cycles(void);
-int pipe_max_nf(void);
+int pipe_max_nf(bool wide);            /* FIR waves per workgroup: narrow 4 (16 frames), wide 8 (32 frames) */
 int prepare_pipe_kernel(void);
-int launch_rx_fused_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s);
+int launch_rx_fused_pipe(const FusedArgs &a, int NF, bool wide, int *status, hipStream_t s);
 int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s);

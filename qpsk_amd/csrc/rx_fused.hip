@@ -45,25 +45,73 @@ namespace qpsk {
 
 namespace pipe {
 
-constexpr int C = 8;             /* CYCLES this instantiation is built for */
-constexpr int R = 4;             /* symbols per FIR lane per chunk */
-constexpr int QL = 16;           /* lanes per frame */
-constexpr int FWV = 64 / QL;     /* frames per FIR wave */
-constexpr int S = R * QL;        /* symbols per chunk */
-constexpr int CH = S * C;        /* samples per chunk per frame */
-constexpr int TSTEPS = NTAPS + C * (R - 1);
-constexpr int WL = CH + 128;     /* window positions kept per frame */
-constexpr int WSLOTS = ((WL + WL / 32 + 1 + 31) / 32) * 32 + 16; /* padded, frame stride = 16 (mod 32) slots */
+typedef float v2f __attribute__((ext_vector_type(2)));   /* one VGPR pair: operand type of the packed fp32 ops */
+
+template <int I>
+struct IntC { static constexpr int value = I; };
+
+/* f(IntC<I>{}) for I = FIRST .. LAST-1, expanded at compile time */
+template <int FIRST, int LAST, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (FIRST < LAST) {
+        f(IntC<FIRST>{});
+        static_for<FIRST + 1, LAST>(f);
+    }
+}
+
+constexpr int C = 8;            /* CYCLES this instantiation is built for */
 constexpr int DR = 2;            /* depth of the symbol rings in chunks */
-constexpr int DSTRIDE = DR * S + 2;   /* float2 slots per frame row: 16-byte aligned rows (the Costas wave reads two symbols
-                                         per ds_read_b128), 4 dwords (mod 64) apart so 16 lanes hit 16 different bank quads */
-constexpr int ZSTRIDE = DR * S + 1;   /* 16-byte records (T.x, T.y, n, -) per Costas row */
-constexpr int MAX_NF = 4;
+constexpr int MAX_WAVES = 8;     /* FIR waves of the widest geometry */
 constexpr int SPIN_LIMIT = 1 << 24;
+
+/*
+ * Two geometries of the same pipeline, chosen by the host from the batch size.  A lone wave on a SIMD issues
+ * the FIR's packed multiply/add stream at ~8 cycles per instruction, two waves together at ~4 [measured: a
+ * wave doing 4 frames alone and a pair doing 8 on the next SIMD finish together], so FIR throughput wants two
+ * waves per SIMD, and the LDS (window + rings per frame) decides how many frames that is:
+ *   Geom<16, 4>  lane = (frame of 4) x (q of 16), 4 symbols per lane: chunks of 64 symbols, 8.6 KB of LDS per
+ *                frame, 4 FIR waves = 16 frames per workgroup.  A batch of up to 16 frames per CU (config 2:
+ *                4096 frames) is bounded by the recurrence, not by the FIR: the serial wave gets a SIMD of
+ *                its own (a spare wave retires at once) and three SIMDs filter.
+ *   Geom<16, 2>  2 symbols per lane: chunks of 32 symbols, 5.0 KB per frame, 8 FIR waves = 32 frames per
+ *                workgroup (two FIR waves per SIMD), the serial wave carries 32 loops for the price of 16.
+ *                11 % more FIR instructions per symbol (135 window reads per 2 symbols instead of 151 per 4).
+ *                Bigger batches (config 4: 8192 frames per GPU) are bounded by the FIR waves.
+ */
+template <int QL_, int R_, int MAX_NF_, int SPARE_>
+struct Geom {
+    static constexpr int QL = QL_;           /* lanes per frame */
+    static constexpr int R = R_;             /* symbols per FIR lane per chunk */
+    static constexpr int MAX_NF = MAX_NF_;   /* FIR waves per workgroup */
+    static constexpr int SPARE = SPARE_;     /* 1: with MAX_NF FIR waves, launch one more wave that retires at once */
+    static constexpr int FWV = 64 / QL;      /* frames per FIR wave */
+    static constexpr int S = R * QL;         /* symbols per chunk */
+    static constexpr int CH = S * C;         /* samples per chunk per frame */
+    static constexpr int TSTEPS = NTAPS + C * (R - 1);   /* window positions a lane sweeps per chunk */
+    static constexpr int PAD = R * C;        /* lanes of a frame are PAD positions apart: position p lives at slot p + p/PAD */
+    static constexpr int WL = CH + 128;      /* window positions kept per frame */
+    /* padded; frame stride = 16 (mod 32) slots: the two frames of a 32-lane LDS pass use complementary banks */
+    static constexpr int WSLOTS = ((WL + WL / PAD + 1 + 31) / 32) * 32 + 16;
+    static constexpr int DSTRIDE = DR * S + 2;   /* float2 slots per frame row: 16-byte aligned rows (the Costas wave reads two
+                                                    symbols per ds_read_b128), 4 dwords (mod 64) apart: lanes hit different bank quads */
+    static constexpr int ZSTRIDE = DR * S + 1;   /* 16-byte records (T.x, T.y, n, -) per Costas row */
+    static constexpr int MAX_THREADS = 64 * (MAX_NF + 1 + SPARE);
+    static_assert(QL == 16 && 64 % QL == 0 && 128 % PAD == 0, "slot arithmetic assumes 16 lanes per frame");
+};
+using GeomNarrow = Geom<16, 4, 4, 1>;
+using GeomWide = Geom<16, 2, 8, 0>;
+
+#define QPSK_GEOM_CONSTANTS(GM)                                                                          \
+    constexpr int QL = GM::QL, R = GM::R, FWV = GM::FWV, S = GM::S, CH = GM::CH, WSLOTS = GM::WSLOTS,    \
+                  DSTRIDE = GM::DSTRIDE, ZSTRIDE = GM::ZSTRIDE, TSTEPS = GM::TSTEPS, PAD = GM::PAD,      \
+                  MAX_NF = GM::MAX_NF;                                                                   \
+    (void)QL; (void)R; (void)FWV; (void)S; (void)CH; (void)WSLOTS; (void)DSTRIDE; (void)ZSTRIDE;         \
+    (void)TSTEPS; (void)PAD; (void)MAX_NF
 
 struct Smem {
     float taps[128];
-    int ready[MAX_NF];        /* chunks produced, per FIR wave */
+    int ready[MAX_WAVES];     /* chunks produced, per FIR wave */
     int consumed;             /* chunks consumed by the Costas wave */
     int abort_flag;
     int pad_[2];
@@ -106,9 +154,11 @@ using namespace pipe;
  * ring, then publishes consumed = c + 1.  Shared by rx_fused_pipe_kernel (ring fed by FIR waves) and
  * costas_pipe_kernel (ring fed from already decimated symbols in global memory).
  */
+template <class GM>
 __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const float2 *dring, float4 *zring, int G,
                                             int f0, int lane, int nchunks, int *status)
 {
+    QPSK_GEOM_CONSTANTS(GM);
     const int nbw = a.nbw, N = a.nsym;
     /* =============================== Costas + slicer wave ===================================== */
     __builtin_amdgcn_s_setprio(3);
@@ -215,8 +265,10 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
  * record (T, n) -> z = T (-j)^(n&3) = costas_frame[] (qpsk.c:197), slicer (qpsk.c:74-79), 4 symbols per
  * 32-bit store.
  */
+template <class GM>
 __device__ __forceinline__ void flush_records(const FusedArgs &a, const float4 *zring, int g, int frame, int q, int chunk)
 {
+    QPSK_GEOM_CONSTANTS(GM);
     const int nbw = a.nbw, N = a.nsym;
     const int slot = (chunk % DR) * S, sym0 = chunk * S;
     const int cnt = min(S, N - sym0);
@@ -232,8 +284,9 @@ __device__ __forceinline__ void flush_records(const FusedArgs &a, const float4 *
             packed |= (uint32_t)slicer(z[r]) << (8 * r);
         }
         if (a.sym) {
-            if (R * q + R <= cnt && ((N | sym0) & 3) == 0) {
-                *reinterpret_cast<uint32_t *>(a.sym + o) = packed;
+            if (R * q + R <= cnt && ((N | sym0) & (R - 1)) == 0) {   /* o is a multiple of R: one aligned store */
+                if constexpr (R == 4) *reinterpret_cast<uint32_t *>(a.sym + o) = packed;
+                else *reinterpret_cast<uint16_t *>(a.sym + o) = (uint16_t)packed;
             } else {
                 for (int r = 0; r < R; r++)
                     if (R * q + r < cnt) a.sym[o + r] = (uint8_t)(packed >> (8 * r));
@@ -254,9 +307,12 @@ __device__ __forceinline__ void flush_records(const FusedArgs &a, const float4 *
  * memory into the symbol ring, and the flush of consumed records.
  * a.dsrc rows are a.dstride symbols apart; one loop per frame (nbw = 1).
  * ======================================================================== */
-__global__ void __launch_bounds__(64 * (MAX_NF + 1))
+__global__ void __launch_bounds__(64 * (GeomNarrow::MAX_NF + 1))
 costas_pipe_kernel(FusedArgs a, int *status)
 {
+    using GM = GeomNarrow;
+    QPSK_GEOM_CONSTANTS(GM);
+    static_assert(R == 2 || R == 4, "flush_records packs 2 or 4 symbols per store");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem *sm = reinterpret_cast<Smem *>(smem_raw);
     const int NF = (int)blockDim.x / 64 - 1;
@@ -267,12 +323,12 @@ costas_pipe_kernel(FusedArgs a, int *status)
     const int N = a.nsym;
     const int f0 = blockIdx.x * G;
     const int nchunks = (N + S - 1) / S;
-    if (tid < MAX_NF) sm->ready[tid] = 0;
+    if (tid < MAX_WAVES) sm->ready[tid] = 0;
     if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
     __syncthreads();
 
     if (wave == 0) {
-        costas_wave(a, sm, dring, zring, G, f0, lane, nchunks, status);
+        costas_wave<GM>(a, sm, dring, zring, G, f0, lane, nchunks, status);
         return;
     }
     const int w = wave - 1;
@@ -295,7 +351,7 @@ costas_pipe_kernel(FusedArgs a, int *status)
             ok = wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag);
             if (!ok) break;
             for (; flushed < c - DR + 1; flushed++)
-                if (fvalid) flush_records(a, zring, g, frame, q, flushed);
+                if (fvalid) flush_records<GM>(a, zring, g, frame, q, flushed);
         }
         float2 *dw = dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q;
 #pragma unroll
@@ -308,20 +364,22 @@ costas_pipe_kernel(FusedArgs a, int *status)
         ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
         if (ok)
             for (; flushed < nchunks; flushed++)
-                if (fvalid) flush_records(a, zring, g, frame, q, flushed);
+                if (fvalid) flush_records<GM>(a, zring, g, frame, q, flushed);
     }
     if (!ok && lane == 0) atomicExch(status, 1);
 }
 
-__global__ void __launch_bounds__(64 * (MAX_NF + 2))
+template <class GM>
+__global__ void __launch_bounds__(GM::MAX_THREADS)
 rx_fused_pipe_kernel(FusedArgs a, int *status)
 {
+    QPSK_GEOM_CONSTANTS(GM);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem *sm = reinterpret_cast<Smem *>(smem_raw);
-    /* With 4 FIR waves the workgroup would be 5 waves on 4 SIMDs and the serial wave would share its SIMD
-     * (waves are dealt round-robin, so wave 4 lands beside wave 0).  The host then launches a sixth wave and
-     * wave 4 retires at once: measured -6 % kernel time (sweep QPSK_PIPE_NOSPARE=1). */
-    const int spare = (a.dbg & 4) ? 0 : ((int)blockDim.x / 64 == MAX_NF + 2 ? 1 : 0);
+    /* Narrow geometry: with 4 FIR waves the workgroup would be 5 waves on 4 SIMDs and the serial wave would
+     * share its SIMD (waves are dealt round-robin, so wave 4 lands beside wave 0).  The host then launches a
+     * sixth wave and wave 4 retires at once: measured -6 % kernel time (sweep QPSK_PIPE_DBG=4). */
+    const int spare = (GM::SPARE && !(a.dbg & 4) && (int)blockDim.x / 64 == MAX_NF + 2) ? 1 : 0;
     const int NF = (int)blockDim.x / 64 - 1 - spare;
     const int G = NF * FWV;
     const int nbw = a.nbw;
@@ -330,7 +388,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     float4 *zring = reinterpret_cast<float4 *>(dring + (size_t)G * DSTRIDE); /* [G*nbw][ZSTRIDE] records (T.x, T.y, n, -):
                                                                                T = d*(C - jS), quadrant = n & 3, see costas_step_t */
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* scalar: per-wave frame pointers stay in SGPRs */
     const int L = a.frame_size, N = a.nsym;
     const int f0 = blockIdx.x * G;
     const int nchunks = (N + S - 1) / S;
@@ -338,14 +397,14 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     /* ---- common prologue: taps, counters, zeroed windows (= fresh delay lines, qpsk.c:37) */
     for (int i = tid; i < 128; i += blockDim.x)
         sm->taps[i] = i < NTAPS ? a.taps[i] : 0.0f;
-    if (tid < MAX_NF) sm->ready[tid] = 0;
+    if (tid < MAX_WAVES) sm->ready[tid] = 0;
     if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
     for (int i = tid; i < G * WSLOTS; i += blockDim.x)
         win[i] = make_float2(0.0f, 0.0f);
     __syncthreads();
 
     if (wave == 0) {
-        costas_wave(a, sm, dring, zring, G, f0, lane, nchunks, status);
+        costas_wave<GM>(a, sm, dring, zring, G, f0, lane, nchunks, status);
         return;
     }
 
@@ -362,7 +421,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     const float4 *taps4 = reinterpret_cast<const float4 *>(sm->taps);
 
     float2 *wf = win + (size_t)g * WSLOTS;                 /* this frame's window */
-    const float2 *rd = wf + 33 * q;                        /* FIR read base: position 32q -> slot 33q */
+    const float2 *rd = wf + (PAD + 1) * q;                 /* FIR read base: position PAD*q -> slot (PAD+1)*q */
     /* write bases: loaded pair (s, s+1), s = 2*l16... one 16-byte load covers 128 samples of ONE frame, so the
      * wave's 64 lanes sweep a frame in 4 loads; lane `lane` holds samples 2*lane, 2*lane+1 of each 128-block */
     const float4 *src_frame[FWV];
@@ -372,8 +431,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         const int fr = f0 + w * FWV + ff;
         const int ix = a.index ? (fr < a.nframes ? a.index[fr] : 0) : a.fixed_index;
         const int p0 = 2 * lane + 126 - ix;               /* window position of sample 2*lane of the chunk */
-        wr0[ff] = (w * FWV + ff) * WSLOTS + p0 + (p0 >> 5);
-        wr1[ff] = (w * FWV + ff) * WSLOTS + (p0 + 1) + ((p0 + 1) >> 5);
+        wr0[ff] = (w * FWV + ff) * WSLOTS + p0 + p0 / PAD;
+        wr1[ff] = (w * FWV + ff) * WSLOTS + (p0 + 1) + (p0 + 1) / PAD;
         src_frame[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(fr < a.nframes ? fr : 0) * L);
     }
     constexpr int NLD = CH / 128;                          /* 16-byte loads per frame per chunk */
@@ -413,7 +472,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
 
     auto flush_upto = [&](int upto) {
         for (; flushed < upto; flushed++)
-            if (fvalid) flush_records(a, zring, g, frame, q, flushed);
+            if (fvalid) flush_records<GM>(a, zring, g, frame, q, flushed);
     };
 
     for (int c = 0; c < nchunks; c++) {
@@ -425,53 +484,102 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         }
         /* history: positions [0, 126-idx) <- [CH, CH+126-idx) of the previous window (zeros for c = 0) */
         {
-            float2 h[8];
+            constexpr int HN = 128 / QL;      /* 128 positions by the frame's QL lanes: p = q + QL*i -> slot p + p/PAD */
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                h[i] = wf[CH + CH / 32 + q + 16 * i + (i >> 1)];
+            for (int i0 = 0; i0 < HN; i0 += 8) {   /* 8 at a time (source and destination ranges are disjoint) */
+                float2 h[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                wf[q + 16 * i + (i >> 1)] = h[i];
+                for (int i = 0; i < 8; i++)
+                    h[i] = wf[CH + CH / PAD + q + QL * (i0 + i) + (QL * (i0 + i)) / PAD];
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    wf[q + QL * (i0 + i) + (QL * (i0 + i)) / PAD] = h[i];
+            }
         }
         /* new samples of this chunk (prefetched), then start the next chunk's loads */
 #pragma unroll
         for (int ff = 0; ff < FWV; ff++) {
 #pragma unroll
             for (int j = 0; j < NLD; j++) {
-                win[wr0[ff] + 132 * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
-                win[wr1[ff] + 132 * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
+                win[wr0[ff] + (128 + 128 / PAD) * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
+                win[wr1[ff] + (128 + 128 / PAD) * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
             }
         }
         if (c + 1 < nchunks) prefetch(c + 1);
 
-        /* sliding-window FIR: symbol r of this lane uses tap k = t - C*r at window position 32q + t */
+        /* sliding-window FIR: symbol r of this lane uses tap k = t - C*r at window position PAD*q + t */
         float2 acc[R];
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = (a.dbg & 1) ? make_float2(0.7f, 0.3f) : make_float2(0.0f, 0.0f);
         /* t = C*tb + u: symbol r needs tap group tb - r (taps C*(tb-r) .. +C-1), so each group of C taps is
-         * live for R consecutive blocks: group tb is fetched at block tb into slot tb % R */
-        static_assert(C == 8 && R == 4, "tap group rotation below is written for C = 8, R = 4");
-        float tg[R][C];
-        if (!(a.dbg & 1)) /* ablation knob (QPSK_PIPE_DBG bit 0): skip the filter arithmetic, keep the traffic */
-#pragma unroll
-        for (int tb = 0; tb * C < TSTEPS; tb++) {
+         * live for R consecutive blocks */
+        static_assert(C == 8 && (R == 4 || R == 2), "the step below is written for C = 8 and R = 2 or 4");
+        /* Software pipeline, one block of C window positions deep: the LDS reads of block tb+1 (window values
+         * and tap group) are issued before the multiply-adds of block tb.  Groups rotate through R + 1 slots so
+         * that the group fetched a block early does not overwrite the one symbol R-1 still needs. */
+        constexpr int NB = (TSTEPS + C - 1) / C;
+        float tg[R + 1][C];
+        float2 wv[2][C];
+        auto fetch_block = [&](int tb) {
             if (tb * C < NTAPS) {
                 const float4 ta = taps4[2 * tb], tb4 = taps4[2 * tb + 1];
-                tg[tb % R][0] = ta.x; tg[tb % R][1] = ta.y; tg[tb % R][2] = ta.z; tg[tb % R][3] = ta.w;
-                tg[tb % R][4] = tb4.x; tg[tb % R][5] = tb4.y; tg[tb % R][6] = tb4.z; tg[tb % R][7] = tb4.w;
+                float *g_ = tg[tb % (R + 1)];
+                g_[0] = ta.x; g_[1] = ta.y; g_[2] = ta.z; g_[3] = ta.w;
+                g_[4] = tb4.x; g_[5] = tb4.y; g_[6] = tb4.z; g_[7] = tb4.w;
             }
 #pragma unroll
             for (int u = 0; u < C; u++) {
                 const int t = tb * C + u;
-                if (t < TSTEPS) {
-                    const float2 v = rd[t + (t >> 5)];
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int k = t - C * r;
-                        if (k >= 0 && k < NTAPS) fir_mac(acc[r], v, tg[(tb - r + R) % R][u]);
-                    }
-                }
+                if (t < TSTEPS) wv[tb & 1][u] = rd[t + t / PAD];
             }
+        };
+        if (!(a.dbg & 1)) { /* ablation knob (QPSK_PIPE_DBG bit 0): skip the filter arithmetic, keep the traffic */
+            /* Instruction order inside a step is pinned with empty asm statements (they keep their program order
+             * and every value they name must exist where they stand): the R products of a step, then the R
+             * adds.  A product is then R instructions ahead of its add and an accumulator's adds are 2R apart,
+             * more than the ~8 cycles a dependent packed op waits, so a lone wave issues back to back. */
+            v2f ac[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) ac[r] = v2f{acc[r].x, acc[r].y};
+            fetch_block(0);
+            /* static_for: the compiler does not unroll a loop with an asm statement in it */
+            static_for<0, NB>([&](auto tbc) {
+                constexpr int tb = decltype(tbc)::value;
+                if (tb + 1 < NB) fetch_block(tb + 1);
+                static_for<0, C>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    constexpr int t = tb * C + u;
+                    if constexpr (t < TSTEPS) {
+                        const v2f v = v2f{wv[tb & 1][u].x, wv[tb & 1][u].y};
+                        constexpr bool ok0 = t < NTAPS, ok1 = t >= C && t - C < NTAPS,
+                                       ok2 = R > 2 && t >= 2 * C && t - 2 * C < NTAPS,
+                                       ok3 = R > 2 && t >= 3 * C && t - 3 * C < NTAPS;
+                        v2f p0, p1, p2, p3;    /* re*tap, im*tap (rrc_fir.c:24-25) */
+                        if constexpr (ok0) p0 = v * tg[(tb + (R + 1)) % (R + 1)][u];
+                        if constexpr (ok1) p1 = v * tg[(tb - 1 + (R + 1)) % (R + 1)][u];
+                        if constexpr (ok2) p2 = v * tg[(tb - 2 + (R + 1)) % (R + 1)][u];
+                        if constexpr (ok3) p3 = v * tg[(tb - 3 + (R + 1)) % (R + 1)][u];
+                        if constexpr (ok0 && ok1 && ok2 && ok3) {
+                            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+                        } else if constexpr (R == 2 && ok0 && ok1) {
+                            asm volatile("" : "+v"(p0), "+v"(p1));
+                        } else {
+                            if constexpr (ok0) asm volatile("" : "+v"(p0));
+                            if constexpr (ok1) asm volatile("" : "+v"(p1));
+                            if constexpr (ok2) asm volatile("" : "+v"(p2));
+                            if constexpr (ok3) asm volatile("" : "+v"(p3));
+                        }
+                        if constexpr (ok0) ac[0] = ac[0] + p0;
+                        if constexpr (ok1) ac[1] = ac[1] + p1;
+                        if constexpr (ok2) ac[2] = ac[2] + p2;
+                        if constexpr (ok3) ac[3] = ac[3] + p3;
+                        if constexpr (R == 4) asm volatile("" : "+v"(ac[0]), "+v"(ac[1]), "+v"(ac[2]), "+v"(ac[3]));
+                        else asm volatile("" : "+v"(ac[0]), "+v"(ac[1]));
+                    }
+                });
+            });
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = make_float2(ac[r].x, ac[r].y);
         }
         /* decimated symbols -> ring; a pick at or past the end of the block is 0 (cannot happen for idx < C) */
         float2 *dw = dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q;
@@ -488,33 +596,46 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     (void)idx;
 }
 
-size_t pipe_lds_bytes(int NF, int nbw, bool want_costas)
+template <class GM>
+static size_t lds_bytes_of(int NF, int nbw)
 {
-    const size_t G = (size_t)NF * FWV;
-    (void)want_costas;
-    size_t b = sizeof(Smem) + sizeof(float2) * (G * WSLOTS + G * DSTRIDE) + sizeof(float4) * G * nbw * ZSTRIDE;
+    const size_t G = (size_t)NF * GM::FWV;
+    size_t b = sizeof(Smem) + sizeof(float2) * (G * GM::WSLOTS + G * GM::DSTRIDE) + sizeof(float4) * G * nbw * GM::ZSTRIDE;
     return (b + 15) & ~(size_t)15;
 }
 
-int pipe_frames_per_wave(void) { return FWV; }
-int pipe_cycles(void) { return C; }
-int pipe_max_nf(void) { return MAX_NF; }
-
-int launch_rx_fused_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
+size_t pipe_lds_bytes(int NF, int nbw, bool wide)
 {
-    const int G = NF * FWV;
+    return wide ? lds_bytes_of<GeomWide>(NF, nbw) : lds_bytes_of<GeomNarrow>(NF, nbw);
+}
+
+int pipe_frames_per_wave(bool wide) { return wide ? GeomWide::FWV : GeomNarrow::FWV; }
+int pipe_cycles(void) { return C; }
+int pipe_max_nf(bool wide) { return wide ? GeomWide::MAX_NF : GeomNarrow::MAX_NF; }
+
+int launch_rx_fused_pipe(const FusedArgs &a, int NF, bool wide, int *status, hipStream_t s)
+{
+    const int G = NF * pipe_frames_per_wave(wide);
     const int blocks = (a.nframes + G - 1) / G;
-    const size_t lds = pipe_lds_bytes(NF, a.nbw, a.costas != nullptr);
-    hipLaunchKernelGGL(rx_fused_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1 + ((NF == MAX_NF && !(a.dbg & 4)) ? 1 : 0))), lds, s, a, status);
+    const size_t lds = pipe_lds_bytes(NF, a.nbw, wide);
+    if (NF < 1 || NF > pipe_max_nf(wide) || lds > (size_t)MAX_LDS_BYTES || G * a.nbw > 64) return (int)hipErrorInvalidValue;
+    if (wide) {
+        /* 9 waves: two FIR waves per SIMD, the serial wave (at higher priority) is the third one on SIMD 0 */
+        hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomWide>, dim3(blocks), dim3(64 * (NF + 1)), lds, s, a, status);
+    } else {
+        hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrow>, dim3(blocks),
+                           dim3(64 * (NF + 1 + ((NF == GeomNarrow::MAX_NF && !(a.dbg & 4)) ? 1 : 0))), lds, s, a, status);
+    }
     hipError_t e = hipGetLastError();
     return (int)e;
 }
 
 int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
 {
-    const int G = NF * FWV;
+    using GM = GeomNarrow;
+    const int G = NF * GM::FWV;
     const int blocks = (a.nframes + G - 1) / G;
-    const size_t lds = sizeof(Smem) + sizeof(float2) * (size_t)G * DSTRIDE + sizeof(float4) * (size_t)G * ZSTRIDE;
+    const size_t lds = sizeof(Smem) + sizeof(float2) * (size_t)G * GM::DSTRIDE + sizeof(float4) * (size_t)G * GM::ZSTRIDE;
     hipLaunchKernelGGL(costas_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1)), lds, s, a, status);
     return (int)hipGetLastError();
 }
@@ -524,7 +645,10 @@ int prepare_pipe_kernel(void)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(costas_pipe_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomWide>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomNarrow>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
 }
 

@@ -131,6 +131,28 @@ def test_rx_batch_tilings_agree(oracle, monkeypatch):
         assert_batch_equal(got, want)
 
 
+@pytest.mark.parametrize("L,mode", [(2048, TIMING_FIXED), (1000, TIMING_FIXED), (2048, TIMING_HIST), (16384, TIMING_FIXED)])
+def test_pipeline_geometries_agree(oracle, monkeypatch, L, mode):
+    """the two geometries of the pipeline kernel (4 or 2 symbols per FIR lane: chunks of 64 or 32 symbols, up to 16
+    or 32 frames per workgroup) and every number of FIR waves give the oracle's bits; frame counts are ragged
+    against both"""
+    fs, rs, F = 19200.0, 2400.0, 75
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=mode, fixed_index=5)
+    x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=L, noise=0.05)
+    x[7] = 0.0
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=mode, fixed_index=5, want_costas=True)
+    for wide, nfs in ((0, (1, 2, 3, 4)), (1, (1, 3, 5, 8))):
+        for nf in nfs:
+            monkeypatch.setenv("QPSK_PIPE_WIDE", str(wide))
+            monkeypatch.setenv("QPSK_PIPE_NF", str(nf))
+            got = m.rx_batch(x, want_costas=True)
+            m.sync()
+            assert_batch_equal(got, want)
+            got = m.rx_batch(x[:33], want_costas=False)
+            m.sync()
+            assert bits_equal(cpu(got["sym"]), want["sym"][:33]) and bits_equal(cpu(got["freq"]), want["freq"][:33])
+
+
 def test_rx_batch_golden_vectors():
     """straight against the reference's own outputs (tests/golden, generated from the reference)"""
     for name in ("c1small", "c1", "c5small_bw200"):
@@ -196,6 +218,30 @@ def test_full_size_config2_properties(oracle):
     m.sync()
     for k in ("sym", "phase", "freq"):
         assert bits_equal(cpu(a[k]), cpu(r[k])[::-1].copy()), k
+    assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
+
+
+def test_full_size_config4_shard_properties(oracle, monkeypatch):
+    """BASELINE config 4's per-GPU share (8192 frames x 16384 samples, 1 GiB): this batch size takes the wide
+    geometry by itself; (a) a spread sample of frames equals the oracle bit for bit, (b) the narrow geometry
+    forced on the same batch gives the same bits everywhere, (c) every loop ends on the +50 Hz offset."""
+    import torch
+    import bench
+    fs, rs, L, F = bench.FS, bench.RS, 16384, 8192
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=bench.FIXED_INDEX)
+    x = bench.synth_frames_gpu(torch, torch.device("cuda", 0), F, m.taps, seed=11)
+    a = m.rx_batch(x)
+    m.sync()
+    pick = np.unique(np.concatenate([np.arange(0, F, 211), [1, 31, 32, 33, F - 33, F - 32, F - 1]]))
+    want = oracle.rx_batch(x[torch.from_numpy(pick).cuda()].cpu().numpy(), fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED,
+                           fixed_index=bench.FIXED_INDEX)
+    for k in ("sym", "phase", "freq", "hz"):
+        assert bits_equal(cpu(a[k])[pick], want[k]), k
+    monkeypatch.setenv("QPSK_PIPE_WIDE", "0")
+    b = m.rx_batch(x)
+    m.sync()
+    for k in ("sym", "phase", "freq"):
+        assert bits_equal(cpu(a[k]), cpu(b[k])), k
     assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
 
 
