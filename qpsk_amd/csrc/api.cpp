@@ -431,7 +431,8 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
          * narrow workgroups (16 frames, serial wave alone on its SIMD); a bigger one is bounded by the FIR
          * waves and takes the wide ones (32 frames, two FIR waves per SIMD) -- see rx_fused.hip */
         bool wide = nframes > c->ncu * pipe_max_nf(false) * pipe_frames_per_wave(false) &&
-                    pipe_max_nf(true) * pipe_frames_per_wave(true) * nbw <= 64;
+                    pipe_max_nf(true) * pipe_frames_per_wave(true) * nbw <= 64 &&
+                    pipe_lds_bytes(pipe_max_nf(true), nbw, true) <= (size_t)MAX_LDS_BYTES;
         wide = env_int("QPSK_PIPE_WIDE", wide ? 1 : 0) != 0;
         const int full = pipe_max_nf(wide);
         const int fwv = pipe_frames_per_wave(wide);
@@ -440,7 +441,8 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
         nf = env_int("QPSK_PIPE_NF", nf);
         if (nf < 1) nf = 1;
         if (nf > full) nf = full;
-        while (nf > 1 && nf * fwv * nbw > 64) nf--;
+        /* one lane of the serial wave per (frame, loop); record rings grow with the number of loops */
+        while (nf > 1 && (nf * fwv * nbw > 64 || pipe_lds_bytes(nf, nbw, wide) > (size_t)MAX_LDS_BYTES)) nf--;
         if (nf * fwv * nbw > 64 || pipe_lds_bytes(nf, nbw, wide) > (size_t)MAX_LDS_BYTES)
             return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame, wide %d", nf, nbw, (int)wide);
         KERNEL_TRY(launch_rx_fused_pipe(a, nf, wide, c->d_status, c->stream));

@@ -245,6 +245,37 @@ def test_full_size_config4_shard_properties(oracle, monkeypatch):
     assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
 
 
+@pytest.mark.parametrize("mode", [TIMING_FIXED, TIMING_HIST])
+def test_smallest_frames(oracle, monkeypatch, mode):
+    """frames of one symbol up to just over one chunk, one to three frames per call, both pipeline geometries:
+    the ragged ends of every loop in the kernels"""
+    fs, rs = 19200.0, 2400.0
+    for L in (8, 16, 24, 136, 264, 520):
+        m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=mode, fixed_index=7)
+        for F in (1, 3):
+            x = random_frames(F, L, seed=L + F, scale=0.7)
+            want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=mode, fixed_index=7, want_costas=True)
+            for wide in (0, 1):
+                monkeypatch.setenv("QPSK_PIPE_WIDE", str(wide))
+                got = m.rx_batch(x, want_costas=True)
+                m.sync()
+                assert_batch_equal(got, want)
+
+
+def test_two_loops_per_frame_in_the_wide_geometry(oracle, monkeypatch):
+    """several loops per frame in the 32-symbol-chunk geometry (the host sheds FIR waves until the record rings
+    of all loops fit the LDS)"""
+    fs, rs, L, F = 19200.0, 2400.0, 2048, 45
+    bws = [np.float32(TAU / 100.0), np.float32(TAU / 170.0)]
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=3)
+    x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=20.0, base_seed=77, noise=0.05)
+    want = oracle.rx_batch_bw(x, fs, rs, bws, timing_mode=TIMING_FIXED, fixed_index=3)
+    monkeypatch.setenv("QPSK_PIPE_WIDE", "1")
+    got = m.rx_batch_bw(x, bws)
+    m.sync()
+    assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
+
+
 def test_empty_and_bad_calls_are_rejected():
     import torch
     m = modem(fs=19200.0, rs=2400.0, frame_size=1024)
