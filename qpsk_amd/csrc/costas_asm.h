@@ -14,7 +14,8 @@
  *     16-byte record (T.x, T.y, n, -) per ds_write_b128;
  *   - the 2*pi wrap is out of line: the common case falls through one not-taken branch whose compare was
  *     issued several instructions earlier; the wrap block fixes the phase and jumps back;
- *   - the exact-zero test of the detector input is a running min over a group of 8 steps.
+ *   - the exact-zero test of the detector input is a running min over a group of 8 steps; with zeros out of
+ *     the way sgn(T.x) T.y is |T.y| carrying the sign of T.x ^ T.y (one xor, two bit-field inserts, no compares).
  *
  * Arithmetic = costas_step_t() in qpsk_device.h operation for operation: Horner sin/cos polynomials in fp64
  * with fused multiply-adds (the library's form), everything in fp32 unfused (the reference is built without
@@ -78,12 +79,11 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     "v_pk_mul_f32 v[104:105], " DREG ", v[112:113] op_sel:[1,0] op_sel_hi:[0,0]\n\t"                          \
     READ                                                                                                      \
     "v_pk_add_f32 v[114:115], v[100:101], v[104:105] neg_hi:[0,1]\n\t"                                        \
-    "v_cmp_lt_f32_e32 vcc, 0, v114\n\t"                                                                       \
-    "v_cmp_lt_f32_e64 %[tm], 0, v115\n\t"                                                                     \
+    "v_xor_b32_e32 v108, v114, v115\n\t"                      /* sign bit = sgn(T.x) sgn(T.y) (no zeros: v126) */ \
     "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
-    "v_cndmask_b32_e64 v108, -v115, v115, vcc\n\t"                                                            \
-    "v_cndmask_b32_e64 v109, -v114, v114, %[tm]\n\t"                                                          \
-    "v_sub_f32_e32 v106, v108, v109\n\t"                                                                      \
+    "v_bfi_b32 v109, %[absm], v115, v108\n\t"                 /* sgn(T.x) T.y = |T.y| with that sign */          \
+    "v_bfi_b32 v108, %[absm], v114, v108\n\t"                 /* sgn(T.y) T.x */                                  \
+    "v_sub_f32_e32 v106, v109, v108\n\t"                                                                      \
     "v_pk_mul_f32 v[102:103], %[beal], v[106:107] op_sel_hi:[1,0]\n\t"                                        \
     "v_add_f32_e32 v118, " FIN ", v102\n\t"                                                                   \
     "v_add_f32_e32 v119, " PIN ", v118\n\t"                                                                   \
