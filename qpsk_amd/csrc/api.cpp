@@ -73,8 +73,9 @@ struct qpsk_ctx {
     float *s_memory = nullptr, *s_dec = nullptr, *s_loop = nullptr, *s_mixer = nullptr;
     /* transmitters (N2) */
     int ntx = 0;
-    float *t_memory = nullptr, *t_mixer = nullptr;
-    DevBuf tx_a, tx_b;
+    uint8_t *t_hist = nullptr;    /* [ntx][tx_history_symbols()]: the symbols still inside tx_filter */
+    float *t_mixer = nullptr;     /* [ntx][4]: carrier phase and step */
+    DevBuf tx_b;                  /* shaped baseband when the caller does not want it */
 };
 
 static const int MAX_BW = 64;
@@ -217,9 +218,10 @@ static void free_streams(qpsk_ctx *c)
 
 static void free_transmitters(qpsk_ctx *c)
 {
-    hipFree(c->t_memory); hipFree(c->t_mixer); hipFree(c->tx_a.p); hipFree(c->tx_b.p);
-    c->t_memory = c->t_mixer = nullptr;
-    c->tx_a = DevBuf(); c->tx_b = DevBuf();
+    hipFree(c->t_hist); hipFree(c->t_mixer); hipFree(c->tx_b.p);
+    c->t_hist = nullptr;
+    c->t_mixer = nullptr;
+    c->tx_b = DevBuf();
     c->ntx = 0;
 }
 
@@ -680,16 +682,19 @@ int qpsk_tx_reset(qpsk_ctx *c, int nstreams, double tx_hz)
     if (bind(c)) return QPSK_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t n = (size_t)nstreams;
+    const size_t hist_bytes = (size_t)tx_history_symbols() * n;
     if (nstreams != c->ntx) {
-        hipFree(c->t_memory); hipFree(c->t_mixer);
-        c->t_memory = c->t_mixer = nullptr;
+        hipFree(c->t_hist); hipFree(c->t_mixer);
+        c->t_hist = nullptr;
+        c->t_mixer = nullptr;
         c->ntx = 0;
-        if (hipMalloc((void **)&c->t_memory, sizeof(float) * 2 * QPSK_NTAPS * n) != hipSuccess ||
+        if (hipMalloc((void **)&c->t_hist, hist_bytes) != hipSuccess ||
             hipMalloc((void **)&c->t_mixer, sizeof(float) * 4 * n) != hipSuccess)
             return fail(QPSK_ERR_ALLOC, "hipMalloc of transmitter state failed");
         c->ntx = nstreams;
     }
-    HIP_TRY(hipMemsetAsync(c->t_memory, 0, sizeof(float) * 2 * QPSK_NTAPS * n, c->stream));
+    /* memset(tx_filter, 0, ...): no symbol sent yet (code 4), i.e. a delay line of zeros */
+    HIP_TRY(hipMemsetAsync(c->t_hist, 4, hist_bytes, c->stream));
     /* fbb_tx_phase = cmplx(0.0f); fbb_tx_rect = cmplx(TAU * hz / FS)  (qpsk.c:316,320) */
     float rect[2];
     qpsk_host_rect_tx(tx_hz, c->prm.fs, rect);
@@ -708,18 +713,15 @@ int qpsk_tx_symbols(qpsk_ctx *c, const uint8_t *d_symbols, int nsym, int16_t *d_
     if (bind(c)) return QPSK_ERR_HIP;
     const int n = c->ntx, len = nsym * c->cycles;
     const size_t bytes = sizeof(float) * 2 * (size_t)n * len;
-    int rc = ensure(c, c->tx_a, bytes);
-    if (rc) return rc;
     float *shaped = d_baseband;
     if (!shaped) {
-        rc = ensure(c, c->tx_b, bytes);
+        int rc = ensure(c, c->tx_b, bytes);
         if (rc) return rc;
         shaped = (float *)c->tx_b.p;
     }
-    /* qpsk.c:273-282 + 232-238: Gray map and zero-stuffing; :243 rrc_fir(tx_filter, ...); :248-261 up-mix */
-    KERNEL_TRY(launch_tx_map(d_symbols, (float *)c->tx_a.p, (size_t)n * len, c->cycles, c->stream));
-    KERNEL_TRY(launch_rrc_fir((const float *)c->tx_a.p, c->t_memory, shaped, c->d_taps, n, len, c->stream));
-    KERNEL_TRY(launch_delay_line((const float *)c->tx_a.p, c->t_memory, n, len, c->stream));
+    /* qpsk.c:273-282 + 232-238 + 243: Gray map, zero-stuffing and rrc_fir(tx_filter, ...) in one kernel;
+     * :248-261 up-mix */
+    KERNEL_TRY(launch_tx_shape(d_symbols, c->t_hist, c->d_taps, shaped, n, nsym, c->cycles, c->stream));
     if (d_pcm) KERNEL_TRY(launch_tx_upmix(shaped, d_pcm, c->t_mixer, n, len, c->stream));
     return QPSK_OK;
 }

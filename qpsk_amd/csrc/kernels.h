@@ -69,7 +69,9 @@ int launch_crc16(const uint8_t *data, int npackets, int nbytes, uint16_t *crc, h
 int launch_interleave(uint8_t *data, int npackets, int nbytes, unsigned b, int dir, hipStream_t s);
 int launch_scramble(uint8_t *sym, const uint8_t *keystream, int npackets, int nsym, hipStream_t s);
 /* txchain.hip */
-int launch_tx_map(const uint8_t *sym, float *sig, size_t total_samples, int cycles, hipStream_t s);
+int tx_history_symbols(void);          /* symbols of state per transmitter (uint8 each, 4 = none yet) */
+int launch_tx_shape(const uint8_t *sym, uint8_t *hist, const float *taps, float *sig, int nstreams, int nsym,
+                    int cycles, hipStream_t s);   /* shaped baseband of nsym symbols per transmitter; updates hist */
 int launch_tx_upmix(const float *sig, int16_t *pcm, float *state, int nstreams, int length, hipStream_t s);
 int launch_fill_i32(int32_t *p, int n, int32_t v, hipStream_t s);
 int launch_sincos_hash(uint32_t first, uint32_t count, unsigned long long *acc, hipStream_t s);

@@ -1,28 +1,71 @@
 /*
  * txchain.hip -- the transmit side of the reference (qpsk.c:225-285) for a batch of transmitters with carried
- * state: Gray map + zero-stuffing here, the RRC shaping is rrc_fir_kernel (the same
- * function the reference calls, qpsk.c:243), then the carrier up-mix and the int16 conversion.
+ * state: Gray map, zero-stuffing and RRC shaping in one kernel, then the carrier up-mix and
+ * the int16 conversion.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
+#include "qpsk_device.h"
 
 namespace qpsk {
 
-/* qpsk_packet_mod() + the zero-stuffing loop of tx_frame() (qpsk.c:232-238, 273-282): symbol index
- * k = (bits[s] << 1) | bits[s+1] -> constellation[k] (qpsk.c:58-63, 270) at sample i*CYCLES, zeros between */
-__global__ void __launch_bounds__(256)
-tx_map_kernel(const uint8_t *__restrict__ sym, float2 *__restrict__ sig, size_t total_samples, int cycles)
+/*
+ * tx_shape_kernel: qpsk_packet_mod() + the zero-stuffing loop + rrc_fir(tx_filter, ...) (qpsk.c:273-282,
+ * 232-238, 243).  The reference pushes CYCLES-1 zeros per symbol through the 127-tap filter, so 7 of 8 terms of
+ * every output sample are +-0.  Leaving them out gives the same float: the accumulator starts at +0, adding +-0
+ * to +0 gives +0 and adding +-0 to anything else changes nothing (rrc_fir.c:22-26 cannot produce -0).  What is
+ * left is the reference's own term, in its own order, for the ~127/CYCLES taps that meet a symbol: an eighth of
+ * the work of the full filter.  Checked bit for bit against the reference's transmitter (tests/golden/tx_*.npz).
+ *
+ * State per transmitter: its last TXS_HIST symbols (code 4 = none yet), which is what the reference's tx_filter
+ * delay line holds.  grid = (tiles of TXS_TILE symbols, transmitters).
+ */
+constexpr int TXS_THREADS = 256;
+constexpr int TXS_TILE = 256;        /* symbols per workgroup */
+constexpr int TXS_HIST = 128;        /* >= 126 / CYCLES + 1 for every CYCLES >= 1 */
+
+__global__ void __launch_bounds__(TXS_THREADS)
+tx_shape_kernel(const uint8_t *__restrict__ sym, const uint8_t *__restrict__ hist, const float *__restrict__ taps_g,
+                float2 *__restrict__ sig, int nsym, int cycles)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total_samples) return;
-    float2 v = make_float2(0.0f, 0.0f);
-    if (i % cycles == 0) {
-        const int k = sym[i / cycles] & 3;
-        v.x = k == 0 ? 1.0f : (k == 3 ? -1.0f : 0.0f);
-        v.y = k == 1 ? 1.0f : (k == 2 ? -1.0f : 0.0f);
+    __shared__ float taps[128];
+    __shared__ float2 ss[TXS_HIST + TXS_TILE];            /* the symbols as constellation points; (0, 0) = none */
+    const int tid = threadIdx.x, f = blockIdx.y;
+    const int s_first = blockIdx.x * TXS_TILE;            /* first symbol of the tile, call-relative */
+    if (tid < 128) taps[tid] = tid < NTAPS ? taps_g[tid] : 0.0f;
+    for (int u = tid; u < TXS_HIST + TXS_TILE; u += TXS_THREADS) {
+        const int s = s_first - TXS_HIST + u;
+        int k = 4;
+        if (s < 0) k = hist[(size_t)f * TXS_HIST + (TXS_HIST + s)];
+        else if (s < nsym) k = sym[(size_t)f * nsym + s] & 3;
+        /* constellation[] = 1, j, -j, -1 (qpsk.c:58-63) */
+        ss[u] = make_float2(k == 0 ? 1.0f : (k == 3 ? -1.0f : 0.0f), k == 1 ? 1.0f : (k == 2 ? -1.0f : 0.0f));
     }
-    sig[i] = v;
+    __syncthreads();
+    const int n_first = s_first * cycles;
+    const int n_end = min(s_first + TXS_TILE, nsym) * cycles;
+    for (int n = n_first + tid; n < n_end; n += TXS_THREADS) {
+        /* tap i of rrc_fir.c:24-25 meets the input sample n - 126 + i; symbols sit at multiples of CYCLES */
+        const int a = n - (NTAPS - 1);
+        int s = a >= 0 ? (a + cycles - 1) / cycles : -((-a) / cycles);      /* ceil(a / CYCLES) */
+        int i = s * cycles - a;
+        float2 acc = make_float2(0.0f, 0.0f);
+        for (; i < NTAPS; i += cycles, s++)
+            fir_mac(acc, ss[s - s_first + TXS_HIST], taps[i]);   /* the reference's own term, rrc_fir.c:24-25 */
+        sig[(size_t)f * nsym * cycles + n] = fir_gain(acc);
+    }
+}
+
+/* the last TXS_HIST symbols after this call: older ones slide down, the call's symbols follow */
+__global__ void __launch_bounds__(TXS_HIST)
+tx_history_kernel(const uint8_t *__restrict__ sym, uint8_t *hist, int nsym)
+{
+    const int h = threadIdx.x, f = blockIdx.x;
+    const int s = nsym - TXS_HIST + h;                     /* call-relative index of the symbol that lands at h */
+    const uint8_t k = s < 0 ? hist[(size_t)f * TXS_HIST + (TXS_HIST + s)] : (uint8_t)(sym[(size_t)f * nsym + s] & 3);
+    __syncthreads();
+    hist[(size_t)f * TXS_HIST + h] = k;
 }
 
 /* qpsk.c:248-261: phase *= rect; signal *= phase; sample = (int16_t)(crealf(signal) * 16384.0f); then the
@@ -117,10 +160,16 @@ tx_upmix_kernel(const float2 *__restrict__ sig, int16_t *__restrict__ pcm, float
     }
 }
 
-int launch_tx_map(const uint8_t *sym, float *sig, size_t total_samples, int cycles, hipStream_t s)
+int tx_history_symbols(void) { return TXS_HIST; }
+
+int launch_tx_shape(const uint8_t *sym, uint8_t *hist, const float *taps, float *sig, int nstreams, int nsym,
+                    int cycles, hipStream_t s)
 {
-    hipLaunchKernelGGL(tx_map_kernel, dim3((unsigned)((total_samples + 255) / 256)), dim3(256), 0, s, sym,
-                       reinterpret_cast<float2 *>(sig), total_samples, cycles);
+    hipLaunchKernelGGL(tx_shape_kernel, dim3((nsym + TXS_TILE - 1) / TXS_TILE, nstreams), dim3(TXS_THREADS), 0, s, sym,
+                       hist, taps, reinterpret_cast<float2 *>(sig), nsym, cycles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(tx_history_kernel, dim3(nstreams), dim3(TXS_HIST), 0, s, sym, hist, nsym);
     return (int)hipGetLastError();
 }
 
