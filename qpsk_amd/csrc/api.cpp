@@ -489,12 +489,20 @@ int qpsk_rx_batch_bw(qpsk_ctx *c, const float *d_in, int nframes, const float *h
 
 /* Costas + slicer over decimated symbols already in device memory (qpsk.c:196-212): the pipeline kernel with
  * loader waves in place of the FIR waves; the one-lane-per-frame kernel only when QPSK_FUSED_GENERIC is set. */
-static int costas_over_symbols(qpsk_ctx *c, const float *d_symbols, int nframes, int nsym, int dstride, float *d_state,
-                               uint8_t *d_sym, float *d_costas)
+/* Costas + slicer over rows of decimated symbols.  Streaming mode: refill != NULL names the block just filtered
+ * ([nframes][nsym*CYCLES]) and refill_index its timing indices; each row of d_symbols is then replaced by that
+ * block's picks once the loop has taken the old ones (qpsk.c:186-191). */
+static int costas_over_symbols(qpsk_ctx *c, float *d_symbols, int nframes, int nsym, int dstride, float *d_state,
+                               uint8_t *d_sym, float *d_costas, const float *refill = nullptr,
+                               const int32_t *refill_index = nullptr)
 {
     if (env_int("QPSK_FUSED_GENERIC", 0)) {
         KERNEL_TRY(launch_costas(d_symbols, nframes, nsym, dstride, 1, c->d_gains, c->min_freq, c->max_freq, d_state, d_state,
                                  d_sym, d_costas, c->stream));
+        if (refill) {
+            if (dstride != nsym) return fail(QPSK_ERR_ARG, "internal: refill needs packed rows");
+            KERNEL_TRY(launch_decimate(refill, refill_index, d_symbols, nframes, nsym * c->cycles, c->cycles, nsym, c->stream));
+        }
         return QPSK_OK;
     }
     FusedArgs a{};
@@ -502,6 +510,9 @@ static int costas_over_symbols(qpsk_ctx *c, const float *d_symbols, int nframes,
     a.nsym = nsym;
     a.frame_size = nsym * c->cycles;
     a.cycles = c->cycles;
+    a.refill = reinterpret_cast<const float2 *>(refill);
+    a.refill_dst = reinterpret_cast<float2 *>(d_symbols);
+    a.index = refill_index;
     a.gains = c->d_gains;
     a.nbw = 1;
     a.min_freq = c->min_freq;
@@ -557,7 +568,8 @@ int qpsk_costas_batch(qpsk_ctx *c, const float *d_symbols_in, int nframes, int n
     if (nframes <= 0 || nsym <= 0) return fail(QPSK_ERR_ARG, "nframes %d nsym %d", nframes, nsym);
     if (bind(c)) return QPSK_ERR_HIP;
     if (int rg = use_context_gains(c)) return rg;
-    return costas_over_symbols(c, d_symbols_in, nframes, nsym, nsym, d_state, d_sym, d_costas);
+    /* no refill: the rows are only read */
+    return costas_over_symbols(c, const_cast<float *>(d_symbols_in), nframes, nsym, nsym, d_state, d_sym, d_costas);
 }
 
 int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, int n, int inverse)
@@ -584,7 +596,7 @@ int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
         free_streams(c);
         const size_t n = (size_t)nstreams;
         if (hipMalloc((void **)&c->s_memory, sizeof(float) * 2 * QPSK_NTAPS * n) != hipSuccess ||
-            hipMalloc((void **)&c->s_dec, sizeof(float) * 4 * c->nsym * n) != hipSuccess ||
+            hipMalloc((void **)&c->s_dec, sizeof(float) * 2 * c->nsym * n) != hipSuccess ||
             hipMalloc((void **)&c->s_loop, sizeof(float) * 2 * n) != hipSuccess ||
             hipMalloc((void **)&c->s_mixer, sizeof(float) * 4 * n) != hipSuccess) {
             free_streams(c);
@@ -594,7 +606,7 @@ int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
     }
     const size_t n = (size_t)nstreams;
     HIP_TRY(hipMemsetAsync(c->s_memory, 0, sizeof(float) * 2 * QPSK_NTAPS * n, c->stream));
-    HIP_TRY(hipMemsetAsync(c->s_dec, 0, sizeof(float) * 4 * c->nsym * n, c->stream));
+    HIP_TRY(hipMemsetAsync(c->s_dec, 0, sizeof(float) * 2 * c->nsym * n, c->stream));
     HIP_TRY(hipMemsetAsync(c->s_loop, 0, sizeof(float) * 2 * n, c->stream));
     /* fbb_rx_phase = cmplx(0.0f); fbb_rx_rect = cmplxconj(TAU * hz / FS)  (qpsk.c:341-342) */
     float rect[2];
@@ -649,11 +661,10 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
         KERNEL_TRY(launch_fill_i32(idx, n, c->prm.fixed_index, c->stream));
     else
         return fail(QPSK_ERR_ARG, "timing mode %d is not implemented in this build", c->prm.timing_mode);
-    /* qpsk.c:186-191 */
-    KERNEL_TRY(launch_decimate(filt, idx, c->s_dec, n, L, c->cycles, N, c->stream));
-    /* qpsk.c:196-212 over the lower half (= the previous block) */
+    /* qpsk.c:196-212 over decimated_frame[0..N) = the PREVIOUS block's picks, which s_dec holds; qpsk.c:186-191:
+     * this block's picks replace them for the next call */
     if (int rg = use_context_gains(c)) return rg;
-    rc = costas_over_symbols(c, c->s_dec, n, N, 2 * N, c->s_loop, d_sym, d_costas);
+    rc = costas_over_symbols(c, c->s_dec, n, N, N, c->s_loop, d_sym, d_costas, filt, idx);
     if (rc) return rc;
     if (d_index) HIP_TRY(hipMemcpyAsync(d_index, idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
     if (d_phase) HIP_TRY(hipMemcpy2DAsync(d_phase, sizeof(float), c->s_loop, 2 * sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, c->stream));

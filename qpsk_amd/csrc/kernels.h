@@ -22,6 +22,11 @@ struct FusedArgs {
     int dbg;                /* measurement only: 1 = skip FIR arithmetic, 2 = skip the Costas recurrence */
     const float2 *dsrc;     /* costas_pipe_kernel only: decimated symbols, rows dstride symbols apart */
     int dstride;
+    /* costas_pipe_kernel, streaming mode (qpsk.c:186-191): once symbol i of a row has been taken, its slot is
+     * refilled with the next block's pick refill[frame][i*cycles + index[frame]] (0 past the block);
+     * refill rows are frame_size samples apart.  NULL = leave dsrc alone */
+    const float2 *refill;
+    float2 *refill_dst;     /* = dsrc, writable */
     const float *taps;      /* [127] */
     const float *gains;     /* [nbw][2] alpha, beta */
     int nbw;

@@ -488,9 +488,13 @@ costas_kernel(const float2 *__restrict__ d, int nframes, int nsym, int dstride, 
 }
 
 /* ========================================================================
- * decimate_kernel: qpsk.c:186-191.  dec: [nstreams][2*nsym]; the upper half
- * moves down, the new block's picks go to the upper half.  A pick past the
- * block (index >= cycles, Q5) is defined as 0.
+ * decimate_kernel: qpsk.c:186-191 for the generic (non-pipeline) streaming
+ * path.  dec: [nstreams][nsym] holds the block the NEXT call's Costas loop
+ * consumes (the reference's decimated_frame[N..2N), which it moves down at
+ * the start of the next rx_frame); run after this call's Costas kernel has
+ * read the previous content.  A pick past the block (index >= cycles, Q5) is
+ * defined as 0.  The pipeline path refills the slots inside
+ * costas_pipe_kernel instead.
  * ======================================================================== */
 __global__ void __launch_bounds__(256)
 decimate_kernel(const float2 *__restrict__ filtered, const int32_t *__restrict__ index, float2 *dec,
@@ -498,11 +502,9 @@ decimate_kernel(const float2 *__restrict__ filtered, const int32_t *__restrict__
 {
     const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
     if (i >= nsym) return;
-    float2 *row = dec + (size_t)f * 2 * nsym;
+    float2 *row = dec + (size_t)f * nsym;
     const int src = i * cycles + index[f];
-    const float2 v = src < frame_size ? filtered[(size_t)f * frame_size + src] : make_float2(0.0f, 0.0f);
-    row[i] = row[nsym + i];
-    row[nsym + i] = v;
+    row[i] = src < frame_size ? filtered[(size_t)f * frame_size + src] : make_float2(0.0f, 0.0f);
 }
 
 /* ========================================================================

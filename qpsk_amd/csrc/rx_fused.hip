@@ -359,6 +359,18 @@ costas_pipe_kernel(FusedArgs a, int *status)
             dw[r] = pre[r];
         if (c + 1 < nchunks) fetch(c + 1);
         if (lane == 0) st_release(&sm->ready[w], c + 1);
+        if (a.refill && fvalid) {
+            /* decimated_frame[i] <- input_frame[i*CYCLES + index] of the block just filtered (qpsk.c:186-191):
+             * the slots this lane has just emptied, off the hand-over path */
+            const float2 *blk = a.refill + (size_t)frame * a.frame_size;
+            float2 *row = a.refill_dst + (size_t)frame * a.dstride;
+            const int ix = a.index ? a.index[frame] : a.fixed_index;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i = c * S + R * q + r, s = i * a.cycles + ix;
+                if (i < N) row[i] = s < a.frame_size ? blk[s] : make_float2(0.0f, 0.0f);
+            }
+        }
     }
     if (ok) {
         ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);

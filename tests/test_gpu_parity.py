@@ -553,7 +553,11 @@ def test_streams_pcm_golden(name):
             assert cpu(o["phase"])[s] == g["phase"][k] and cpu(o["freq"])[s] == g["freq"][k]
 
 
-def test_streams_cplx_vs_oracle(oracle):
+@pytest.mark.parametrize("generic", [0, 1])
+def test_streams_cplx_vs_oracle(oracle, monkeypatch, generic):
+    """generic = 1: the barrier-synchronised kernels (decimate_kernel + costas_kernel) instead of the pipeline"""
+    if generic:
+        monkeypatch.setenv("QPSK_FUSED_GENERIC", "1")
     fs, rs, L, S = 19200.0, 2400.0, 1024, 9
     m = modem(fs=fs, rs=rs, frame_size=L)
     m.streams_reset(S)
