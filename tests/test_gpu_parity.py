@@ -262,6 +262,42 @@ def test_smallest_frames(oracle, monkeypatch, mode):
                 assert_batch_equal(got, want)
 
 
+def test_randomised_configurations(oracle, monkeypatch):
+    """a fixed-seed sweep over frame sizes, frame counts, amplitudes, loop bandwidths, clamps, timing modes and
+    pipeline geometries: every output bit against the oracle (rare paths: 2 pi wraps, active clamp, exact zeros,
+    ragged chunks and workgroups)"""
+    rng = np.random.default_rng(20261004)
+    fs, rs = 19200.0, 2400.0
+    for case in range(48):
+        L = 8 * int(rng.integers(1, 400))
+        F = int(rng.integers(1, 80))
+        scale = float(10.0 ** rng.uniform(-3, 1.5))
+        bw = np.float32(TAU / rng.uniform(20, 400))
+        lo, hi = (-1.0, 1.0) if case % 3 else (-float(rng.uniform(0.002, 0.3)), float(rng.uniform(0.002, 0.3)))
+        mode = TIMING_HIST if case % 4 == 0 else TIMING_FIXED
+        idx = int(rng.integers(0, 8))
+        if case % 2:
+            x = random_frames(F, L, seed=case, scale=scale)
+        else:
+            m0 = modem(fs=fs, rs=rs, frame_size=L)
+            x, _ = make_frames(F, L, 8, m0.taps, fs, offset_hz=float(rng.uniform(-200, 200)), base_seed=case,
+                               amplitude=scale, noise=0.05 * scale)
+        if case % 5 == 0:
+            x[rng.integers(0, F)] = 0.0
+        m = modem(fs=fs, rs=rs, frame_size=L, loop_bw=bw, min_freq=lo, max_freq=hi, timing_mode=mode, fixed_index=idx)
+        want = oracle.rx_batch(x, fs, rs, loop_bw=bw, min_freq=lo, max_freq=hi, timing_mode=mode, fixed_index=idx,
+                               want_costas=True)
+        monkeypatch.setenv("QPSK_PIPE_WIDE", str(case % 2))
+        monkeypatch.setenv("QPSK_PIPE_NF", str(1 + case % 8))
+        got = m.rx_batch(x, want_costas=True)
+        m.sync()
+        try:
+            assert_batch_equal(got, want)
+        except AssertionError as e:
+            raise AssertionError("case %d (L %d, F %d, scale %g, bw %g, clamp %g..%g, mode %d, index %d): %s" % (
+                case, L, F, scale, bw, lo, hi, mode, idx, e))
+
+
 def test_two_loops_per_frame_in_the_wide_geometry(oracle, monkeypatch):
     """several loops per frame in the 32-symbol-chunk geometry (the host sheds FIR waves until the record rings
     of all loops fit the LDS)"""
