@@ -340,9 +340,14 @@ void qo_modem_set_mixer(qo_modem *m, const float *pr)
 static void rx_tail(qo_modem *m)
 {
     const int N = m->nsym, C = m->cycles, L = m->frame_size;
+    /* the FFT estimate (new design, see qo_timing_fft_index) looks at the block BEFORE the filter and, starting
+     * at sample 128, never reaches back into the carried delay line: it is the same function of the block in
+     * the streaming mode as for an independent frame */
+    const int fft_index = m->timing_mode == QO_TIMING_FFT ? qo_timing_fft_index(m->taps, m->input_frame, L, C) : 0;
     qo_rrc_fir(m->taps, m->rx_filter, m->input_frame, L);
 
     int index = (m->timing_mode == QO_TIMING_FIXED) ? m->fixed_index
+                : (m->timing_mode == QO_TIMING_FFT) ? fft_index
                                                     : qo_timing_index(m->input_frame, L, C);
     m->last_index = index;
 

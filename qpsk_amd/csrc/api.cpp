@@ -659,8 +659,8 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
         KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, nullptr, c->stream));
     else if (c->prm.timing_mode == QPSK_TIMING_FIXED)
         KERNEL_TRY(launch_fill_i32(idx, n, c->prm.fixed_index, c->stream));
-    else
-        return fail(QPSK_ERR_ARG, "timing mode %d is not implemented in this build", c->prm.timing_mode);
+    else if (int rf = fft_timing_indices(c, d_in, n, idx))   /* stateless: it looks at the raw block from sample 2 on */
+        return rf;
     /* qpsk.c:196-212 over decimated_frame[0..N) = the PREVIOUS block's picks, which s_dec holds; qpsk.c:186-191:
      * this block's picks replace them for the next call */
     if (int rg = use_context_gains(c)) return rg;

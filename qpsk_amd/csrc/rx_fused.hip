@@ -19,11 +19,13 @@
  *                    counters in LDS (bounded spins; a timeout is reported through *status);
  *   wave 4           (only when there are 4 FIR waves) exits at once, so that wave 0 does not share a SIMD.
  *
- * FIR wave layout: lane = (frame f of 4) x (q of 16); per chunk of S = 64
+ * FIR wave layout (numbers of the narrow geometry, Geom<16,4,4,1>; the wide
+ * one, Geom<16,2,8,0>, halves R, S and the window, see struct Geom): lane =
+ * (frame f of 4) x (q of 16); per chunk of S = 64
  * symbols the lane produces the R = 4 consecutive symbols 4q..4q+3 of its
  * frame with a sliding window: one 8-byte LDS read feeds up to 4 of the 508
- * multiply-adds, taps come from LDS broadcast reads (4 groups of 8 live at a
- * time), each symbol's taps are summed 0..126 in one fp32 accumulator
+ * multiply-adds, taps come from LDS broadcast reads (R + 1 groups of 8 live at
+ * a time), each symbol's taps are summed 0..126 in one fp32 accumulator
  * (bit-exactness).
  * LDS image of a frame's window: position p (0 = the oldest sample the
  * chunk needs, i.e. sample chunk_start + index - 126) at float2 slot

@@ -589,6 +589,26 @@ def test_streams_pcm_golden(name):
             assert cpu(o["phase"])[s] == g["phase"][k] and cpu(o["freq"])[s] == g["freq"][k]
 
 
+def test_streams_with_fft_timing(oracle):
+    """the FFT timing estimate in the streaming mode: per block, from the raw block (it starts at sample 128 and
+    so never touches the carried delay line); everything downstream carries state as usual"""
+    from oracle.pyoracle import TIMING_FFT
+    fs, rs, L, S = 19200.0, 2400.0, 2048, 5
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT)
+    m.streams_reset(S)
+    om = [oracle.modem(fs, rs, L, loop_bw=BW, timing_mode=TIMING_FFT) for _ in range(S)]
+    x, _ = make_frames(S, L * 4, 8, m.taps, fs, offset_hz=-40.0, base_seed=23, noise=0.03)
+    for k in range(4):
+        blk = np.ascontiguousarray(x[:, k * L:(k + 1) * L])
+        o = m.streams_rx_cplx(blk)
+        m.sync()
+        for s in range(S):
+            om[s].rx_cplx(blk[s])
+            assert cpu(o["index"])[s] == om[s].index
+            assert bits_equal(cpu(o["sym"][s]), om[s].symbols) and bits_equal(cpu(o["costas"][s]), om[s].costas_frame)
+            assert cpu(o["phase"])[s] == om[s].phase and cpu(o["freq"])[s] == om[s].freq
+
+
 @pytest.mark.parametrize("generic", [0, 1])
 def test_streams_cplx_vs_oracle(oracle, monkeypatch, generic):
     """generic = 1: the barrier-synchronised kernels (decimate_kernel + costas_kernel) instead of the pipeline"""
