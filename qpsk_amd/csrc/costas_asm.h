@@ -10,8 +10,8 @@
  * detector -> loop update -> phase); the compiler's version of it ran ~355 cycles per step, the arithmetic
  * chain alone is ~140.  What this stream does about it:
  *   - off-chain work is slotted between the dependent operations;
- *   - LDS traffic is 1.5 instructions per step: two symbols per ds_read_b128 (fetched a step ahead), one
- *     16-byte record (T.x, T.y, n, -) per ds_write_b128;
+ *   - LDS traffic is 1.5 instructions per step: two symbols per ds_read_b128 (fetched two steps ahead into
+ *     alternating register sets), one 16-byte record (T.x, T.y, n, -) per ds_write_b128;
  *   - the 2*pi wrap is out of line: the common case falls through one not-taken branch whose compare was
  *     issued several instructions earlier; the wrap block fixes the phase and jumps back;
  *   - the exact-zero test of the detector input is a running min over a group of 8 steps; with zeros out of
@@ -29,7 +29,7 @@
  *     min(|T.x|, |T.y|) == 0   (the detector's sgn(0) = -1 asymmetry, see costas_step_t)
  *     a phase still outside [-2pi, 2pi] after ONE wrap (clamp wider than +-2pi, huge amplitudes).
  *
- * Registers: v[100:135] are scratch owned by the block (clobbered; low enough for a kernel built for three
+ * Registers: v[100:139] (136:139 = the second pair of decimated symbols) are scratch owned by the block (clobbered; low enough for a kernel built for three
  * waves per SIMD, i.e. at most 168 VGPRs):
  *   100:101 x / d*C      102:103 beta*e, alpha*e   104:105 n / x3 / d*S     106:107 xr / e
  *   108:109 x2 / a, b    110:111 cos chain (v110 = C)   112:113 sin chain (v112 = S)
@@ -106,8 +106,12 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     "s_or_b64 %[fl], %[fl], vcc\n\t"                                                                          \
     "s_branch " LR "b\n"
 
-#define QPSK_WAIT1 "s_waitcnt lgkmcnt(1)\n\t"
-#define QPSK_RD(OFF) "ds_read_b128 v[120:123], %[da] offset:" QPSK_STR(OFF) "\n\t"
+/* symbol pairs alternate between two register sets, each fetched TWO steps before its first use (the FIR waves
+ * keep the LDS queue busy; one step of slack was not always enough): when a set is first used, the two record
+ * writes issued since its read may still be in flight */
+#define QPSK_WAIT2 "s_waitcnt lgkmcnt(2)\n\t"
+#define QPSK_RDA(OFF) "ds_read_b128 v[120:123], %[da] offset:" QPSK_STR(OFF) "\n\t"
+#define QPSK_RDB(OFF) "ds_read_b128 v[136:139], %[da] offset:" QPSK_STR(OFF) "\n\t"
 
 /*
  * Runs up to `groups` groups of 8 steps starting at LDS addresses d_addr (symbols, 8 bytes each, 16-byte
@@ -136,14 +140,14 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         "v_mov_b32 v130, %[p]\n\t"
         "v_mov_b32 v131, %[f]\n\t"
         "v_mov_b32 v126, 0x7f800000\n\t"        /* running min of |T.x|, |T.y| over the group: 0 <=> some exact zero */
-        QPSK_COSTAS_STEP("%[p]", "%[f]", "v132", "v133", "v[120:121]", QPSK_WAIT1, "", 0, "10", "20")
-        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", QPSK_RD(16), 16, "11", "21")
-        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[120:121]", QPSK_WAIT1, "", 32, "12", "22")
-        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", QPSK_RD(32), 48, "13", "23")
-        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[120:121]", QPSK_WAIT1, "", 64, "14", "24")
-        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", QPSK_RD(48), 80, "15", "25")
-        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[120:121]", QPSK_WAIT1, "", 96, "16", "26")
-        QPSK_COSTAS_STEP("v132", "v133", "%[p]", "%[f]", "v[122:123]", "", QPSK_RD(64), 112, "17", "27")
+        QPSK_COSTAS_STEP("%[p]", "%[f]", "v132", "v133", "v[120:121]", QPSK_WAIT2, QPSK_RDB(16), 0, "10", "20")
+        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", "", 16, "11", "21")
+        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[136:137]", QPSK_WAIT2, QPSK_RDA(32), 32, "12", "22")
+        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[138:139]", "", "", 48, "13", "23")
+        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[120:121]", QPSK_WAIT2, QPSK_RDB(48), 64, "14", "24")
+        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", "", 80, "15", "25")
+        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[136:137]", QPSK_WAIT2, QPSK_RDA(64), 96, "16", "26")
+        QPSK_COSTAS_STEP("v132", "v133", "%[p]", "%[f]", "v[138:139]", "", "", 112, "17", "27")
         "v_cmp_eq_f32_e64 %[tm], 0, v126\n\t"
         "s_or_b64 %[fl], %[fl], %[tm]\n\t"
         "s_cmp_lg_u64 %[fl], 0\n\t"
@@ -176,7 +180,8 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
           [c1] "s"(-0x1.ffffffd0c621cp-2), [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
           "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
-          "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135");
+          "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135",
+          "v136", "v137", "v138", "v139");
     flags_out = flags;
     return groups;
 }

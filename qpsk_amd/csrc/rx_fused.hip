@@ -396,7 +396,6 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     const int spare = (GM::SPARE && !(a.dbg & 4) && (int)blockDim.x / 64 == MAX_NF + 2) ? 1 : 0;
     const int NF = (int)blockDim.x / 64 - 1 - spare;
     const int G = NF * FWV;
-    const int nbw = a.nbw;
     float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));   /* [G][WSLOTS] */
     float2 *dring = win + (size_t)G * WSLOTS;                              /* [G][DSTRIDE] */
     float4 *zring = reinterpret_cast<float4 *>(dring + (size_t)G * DSTRIDE); /* [G*nbw][ZSTRIDE] records (T.x, T.y, n, -):
@@ -429,9 +428,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     const int g = w * FWV + fl;             /* frame slot in the workgroup */
     const int frame = f0 + g;
     const bool fvalid = frame < a.nframes;
-    int idx = a.index ? (fvalid ? a.index[frame] : 0) : a.fixed_index;   /* decimation offset, < C */
 
-    /* taps stay in LDS; the FIR loop keeps a rolling set of 4 groups of C taps in registers (broadcast reads) */
+    /* taps stay in LDS; the FIR loop keeps a rolling set of R + 1 groups of C taps in registers (broadcast reads) */
     const float4 *taps4 = reinterpret_cast<const float4 *>(sm->taps);
 
     float2 *wf = win + (size_t)g * WSLOTS;                 /* this frame's window */
@@ -607,7 +605,6 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         if (ok) flush_upto(nchunks);
     }
     if (!ok && lane == 0) atomicExch(status, 1);
-    (void)idx;
 }
 
 template <class GM>

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--per-round", type=int, default=4)
     ap.add_argument("--timing", choices=["fixed", "hist", "fft"], default="fixed")
+    ap.add_argument("--offset-hz", type=float, default=50.0, help="carrier offset of the synthetic frames (sets the 2 pi wrap rate)")
     ap.add_argument("configs", nargs="*", default=[""])
     args = ap.parse_args()
     import torch
@@ -30,7 +31,7 @@ def main():
     F = args.frames
     mode = {"fixed": qpsk_amd.TIMING_FIXED, "hist": qpsk_amd.TIMING_HIST, "fft": qpsk_amd.TIMING_FFT}[args.timing]
     m = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=mode, fixed_index=bench.FIXED_INDEX)
-    x = bench.synth_frames_gpu(torch, dev, F, m.taps, seed=1000)
+    x = bench.synth_frames_gpu(torch, dev, F, m.taps, seed=1000, offset_hz=args.offset_hz)
     sym = torch.empty((F, m.nsym), dtype=torch.uint8, device=dev)
     freq = torch.empty((F,), dtype=torch.float32, device=dev)
     phase = torch.empty((F,), dtype=torch.float32, device=dev)
