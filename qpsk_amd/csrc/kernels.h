@@ -19,7 +19,9 @@ struct FusedArgs {
     int G, S;               /* frames per workgroup, symbols per chunk */
     const int32_t *index;   /* [nframes] or NULL -> fixed_index */
     int fixed_index;
-    int dbg;                /* measurement only: 1 = skip FIR arithmetic, 2 = skip the Costas recurrence */
+    int dbg;                /* measurement only (QPSK_PIPE_DBG): 1 skip FIR arithmetic, 2 skip the Costas recurrence,
+                               4 no spare waves, 8 C++ Costas step, 16 compiler-scheduled FIR step, 32 print the cycle
+                               accounting of workgroup 0's FIR waves */
     const float2 *dsrc;     /* costas_pipe_kernel only: decimated symbols, rows dstride symbols apart */
     int dstride;
     /* costas_pipe_kernel, streaming mode (qpsk.c:186-191): once symbol i of a row has been taken, its slot is

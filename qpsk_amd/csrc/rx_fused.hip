@@ -81,12 +81,13 @@ constexpr int SPIN_LIMIT = 1 << 24;
  *                11 % more FIR instructions per symbol (135 window reads per 2 symbols instead of 151 per 4).
  *                Bigger batches (config 4: 8192 frames per GPU) are bounded by the FIR waves.
  */
-template <int QL_, int R_, int MAX_NF_, int SPARE_>
+template <int QL_, int R_, int MAX_NF_, int SPARE_, bool PINNED_>
 struct Geom {
+    static constexpr bool PINNED = PINNED_;  /* FIR step with the product/add order pinned by hand (see the FIR loop) */
     static constexpr int QL = QL_;           /* lanes per frame */
     static constexpr int R = R_;             /* symbols per FIR lane per chunk */
     static constexpr int MAX_NF = MAX_NF_;   /* FIR waves per workgroup */
-    static constexpr int SPARE = SPARE_;     /* 1: with MAX_NF FIR waves, launch one more wave that retires at once */
+    static constexpr int SPARE = SPARE_;     /* 1: no FIR wave on the serial wave's SIMD (waves 4, 8 are launched and retire at once) */
     static constexpr int FWV = 64 / QL;      /* frames per FIR wave */
     static constexpr int S = R * QL;         /* symbols per chunk */
     static constexpr int CH = S * C;         /* samples per chunk per frame */
@@ -98,11 +99,12 @@ struct Geom {
     static constexpr int DSTRIDE = DR * S + 2;   /* float2 slots per frame row: 16-byte aligned rows (the Costas wave reads two
                                                     symbols per ds_read_b128), 4 dwords (mod 64) apart: lanes hit different bank quads */
     static constexpr int ZSTRIDE = DR * S + 1;   /* 16-byte records (T.x, T.y, n, -) per Costas row */
-    static constexpr int MAX_THREADS = 64 * (MAX_NF + 1 + SPARE);
+    static constexpr int MAX_THREADS = 64 * (MAX_NF + 1 + SPARE * ((MAX_NF - 1) / 3));
     static_assert(QL == 16 && 64 % QL == 0 && 128 % PAD == 0, "slot arithmetic assumes 16 lanes per frame");
 };
-using GeomNarrow = Geom<16, 4, 4, 1>;
-using GeomWide = Geom<16, 2, 8, 0>;
+using GeomNarrow = Geom<16, 4, 4, 1, true>;
+using GeomNarrowAlt = Geom<16, 4, 4, 1, false>;  /* measurement only (QPSK_PIPE_DBG bit 4): the compiler's FIR schedule */
+using GeomWide = Geom<16, 2, 8, 0, true>;        /* spares measured worse here: 3 FIR waves on a SIMD starve the youngest */
 
 #define QPSK_GEOM_CONSTANTS(GM)                                                                          \
     constexpr int QL = GM::QL, R = GM::R, FWV = GM::FWV, S = GM::S, CH = GM::CH, WSLOTS = GM::WSLOTS,    \
@@ -390,11 +392,12 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     QPSK_GEOM_CONSTANTS(GM);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem *sm = reinterpret_cast<Smem *>(smem_raw);
-    /* Narrow geometry: with 4 FIR waves the workgroup would be 5 waves on 4 SIMDs and the serial wave would
-     * share its SIMD (waves are dealt round-robin, so wave 4 lands beside wave 0).  The host then launches a
-     * sixth wave and wave 4 retires at once: measured -6 % kernel time (sweep QPSK_PIPE_DBG=4). */
-    const int spare = (GM::SPARE && !(a.dbg & 4) && (int)blockDim.x / 64 == MAX_NF + 2) ? 1 : 0;
-    const int NF = (int)blockDim.x / 64 - 1 - spare;
+    /* Waves are dealt to the SIMDs round-robin, so waves 4, 8, ... land beside the serial wave 0.  With spare
+     * waves the host launches those too and they retire at once: the serial wave keeps SIMD 0 to itself and the
+     * FIR waves are hardware waves 1,2,3, 5,6,7, 9,10 (QPSK_PIPE_DBG bit 2 turns the spares off). */
+    const bool spares = GM::SPARE && !(a.dbg & 4);
+    const int nwaves = (int)blockDim.x / 64;
+    const int NF = spares ? (nwaves - 1) - (nwaves - 1) / 4 : nwaves - 1;
     const int G = NF * FWV;
     float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));   /* [G][WSLOTS] */
     float2 *dring = win + (size_t)G * WSLOTS;                              /* [G][DSTRIDE] */
@@ -422,8 +425,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     }
 
     /* ======================================= FIR waves =========================================== */
-    if (spare && wave == 4) return;          /* the wave that would share a SIMD with wave 0 */
-    const int w = (spare && wave > 4) ? wave - 2 : wave - 1;   /* FIR wave index */
+    if (spares && (wave & 3) == 0) return;   /* a wave that would share a SIMD with wave 0 */
+    const int w = spares ? wave - 1 - wave / 4 : wave - 1;   /* FIR wave index */
     const int fl = lane / QL, q = lane % QL;
     const int g = w * FWV + fl;             /* frame slot in the workgroup */
     const int frame = f0 + g;
@@ -487,12 +490,26 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
             if (fvalid) flush_records<GM>(a, zring, g, frame, q, flushed);
     };
 
+    /* measurement knob (QPSK_PIPE_DBG bit 5): where a FIR wave of workgroup 0 spends its shader cycles */
+    const bool prof = (a.dbg & 32) && blockIdx.x == 0;
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = 0;
+    auto tick = [&](int k) {
+        if (prof) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            if (k >= 0) tacc[k] += t - tlast;
+            tlast = t;
+        }
+    };
+    tick(-1);
     for (int c = 0; c < nchunks; c++) {
         /* ring slot c % DR is free once chunk c - DR has been consumed; its outputs leave first */
         if (c >= DR) {
             ok = wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag);
             if (!ok) break;
+            tick(0);
             flush_upto(c - DR + 1);
+            tick(1);
         }
         /* history: positions [0, 126-idx) <- [CH, CH+126-idx) of the previous window (zeros for c = 0) */
         {
@@ -518,6 +535,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
             }
         }
         if (c + 1 < nchunks) prefetch(c + 1);
+        tick(2);
 
         /* sliding-window FIR: symbol r of this lane uses tap k = t - C*r at window position PAD*q + t */
         float2 acc[R];
@@ -545,7 +563,33 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                 if (t < TSTEPS) wv[tb & 1][u] = rd[t + t / PAD];
             }
         };
-        if (!(a.dbg & 1)) { /* ablation knob (QPSK_PIPE_DBG bit 0): skip the filter arithmetic, keep the traffic */
+        if constexpr (!GM::PINNED) {
+            /* the compiler's own schedule of the same sum, kept for A/B runs (QPSK_PIPE_DBG bit 4): config 2
+             * 0.2148 ms against 0.2088 ms with the pinned order below [measured, same process] */
+            if (!(a.dbg & 1)) {
+                float tgc[R][C];
+#pragma unroll
+                for (int tb = 0; tb * C < TSTEPS; tb++) {
+                    if (tb * C < NTAPS) {
+                        const float4 ta = taps4[2 * tb], tb4 = taps4[2 * tb + 1];
+                        tgc[tb % R][0] = ta.x; tgc[tb % R][1] = ta.y; tgc[tb % R][2] = ta.z; tgc[tb % R][3] = ta.w;
+                        tgc[tb % R][4] = tb4.x; tgc[tb % R][5] = tb4.y; tgc[tb % R][6] = tb4.z; tgc[tb % R][7] = tb4.w;
+                    }
+#pragma unroll
+                    for (int u = 0; u < C; u++) {
+                        const int t = tb * C + u;
+                        if (t < TSTEPS) {
+                            const float2 v = rd[t + t / PAD];
+#pragma unroll
+                            for (int r = 0; r < R; r++) {
+                                const int k = t - C * r;
+                                if (k >= 0 && k < NTAPS) fir_mac(acc[r], v, tgc[(tb - r + R) % R][u]);
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (!(a.dbg & 1)) { /* ablation knob (QPSK_PIPE_DBG bit 0): skip the filter arithmetic, keep the traffic */
             /* Instruction order inside a step is pinned with empty asm statements (they keep their program order
              * and every value they name must exist where they stand): the R products of a step, then the R
              * adds.  A product is then R instructions ahead of its add and an accumulator's adds are 2R apart,
@@ -593,18 +637,24 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = make_float2(ac[r].x, ac[r].y);
         }
+        tick(3);
         /* decimated symbols -> ring; a pick at or past the end of the block is 0 (cannot happen for idx < C) */
         float2 *dw = dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q;
 #pragma unroll
         for (int r = 0; r < R; r++)
             dw[r] = fir_gain(acc[r]);
         if (lane == 0) st_release(&sm->ready[w], c + 1);
+        tick(4);
     }
     if (ok) {
         ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
         if (ok) flush_upto(nchunks);
     }
     if (!ok && lane == 0) atomicExch(status, 1);
+    if (prof && lane == 0)
+        printf("FIR wave %d: %d chunks; cycles per chunk: wait for the loop %llu, flush %llu, history + window %llu, filter %llu, "
+               "ring hand-over %llu\n", w, nchunks, tacc[0] / nchunks, tacc[1] / nchunks, tacc[2] / nchunks, tacc[3] / nchunks,
+               tacc[4] / nchunks);
 }
 
 template <class GM>
@@ -630,12 +680,16 @@ int launch_rx_fused_pipe(const FusedArgs &a, int NF, bool wide, int *status, hip
     const int blocks = (a.nframes + G - 1) / G;
     const size_t lds = pipe_lds_bytes(NF, a.nbw, wide);
     if (NF < 1 || NF > pipe_max_nf(wide) || lds > (size_t)MAX_LDS_BYTES || G * a.nbw > 64) return (int)hipErrorInvalidValue;
+    /* hardware waves of a workgroup with NF FIR waves: with spares, FIR wave k is hardware wave k + 1 + k/3 */
+    auto nwaves = [&](int spare) { return (spare && !(a.dbg & 4)) ? NF + 1 + (NF - 1) / 3 : NF + 1; };
     if (wide) {
-        /* 9 waves: two FIR waves per SIMD, the serial wave (at higher priority) is the third one on SIMD 0 */
-        hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomWide>, dim3(blocks), dim3(64 * (NF + 1)), lds, s, a, status);
+        hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomWide>, dim3(blocks), dim3(64 * nwaves(GeomWide::SPARE)), lds, s, a, status);
     } else {
-        hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrow>, dim3(blocks),
-                           dim3(64 * (NF + 1 + ((NF == GeomNarrow::MAX_NF && !(a.dbg & 4)) ? 1 : 0))), lds, s, a, status);
+        const dim3 threads(64 * nwaves(GeomNarrow::SPARE));
+        if (a.dbg & 16)   /* measurement knob (QPSK_PIPE_DBG bit 4): the other FIR-step schedule */
+            hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrowAlt>, dim3(blocks), threads, lds, s, a, status);
+        else
+            hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrow>, dim3(blocks), threads, lds, s, a, status);
     }
     hipError_t e = hipGetLastError();
     return (int)e;
@@ -657,6 +711,9 @@ int prepare_pipe_kernel(void)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomWide>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomNarrowAlt>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomNarrow>),
