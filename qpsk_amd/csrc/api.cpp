@@ -426,26 +426,28 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
     /* the pipeline kernel (rx_fused.hip) is built for CYCLES = 8, 16-byte aligned frames and an index
      * below CYCLES; everything else takes the generic chunked kernel (kernels.hip) */
     const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 &&
-                         ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames_per_wave(false) <= 64 &&
+                         ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames(1, false) <= 64 &&
                          !env_int("QPSK_FUSED_GENERIC", 0);
     if (pipe_ok) {
         /* geometry: a batch that leaves at most 16 frames to a CU is bounded by the recurrence and takes the
          * narrow workgroups (16 frames, serial wave alone on its SIMD); a bigger one is bounded by the FIR
          * waves and takes the wide ones (32 frames, two FIR waves per SIMD) -- see rx_fused.hip */
-        bool wide = nframes > c->ncu * pipe_max_nf(false) * pipe_frames_per_wave(false) &&
-                    pipe_max_nf(true) * pipe_frames_per_wave(true) * nbw <= 64 &&
-                    pipe_lds_bytes(pipe_max_nf(true), nbw, true) <= (size_t)MAX_LDS_BYTES;
+        auto fits = [&](int nf_, bool wide_) {   /* one lane of the serial wave per (frame, loop); rings grow with the loops */
+            return pipe_frames(nf_, wide_) * nbw <= 64 && pipe_lds_bytes(nf_, nbw, wide_) <= (size_t)MAX_LDS_BYTES;
+        };
+        bool wide = nframes > c->ncu * pipe_frames(pipe_max_nf(false), false) && fits(pipe_max_nf(true), true);
         wide = env_int("QPSK_PIPE_WIDE", wide ? 1 : 0) != 0;
         const int full = pipe_max_nf(wide);
-        const int fwv = pipe_frames_per_wave(wide);
-        int nf = wide ? full : (nframes + c->ncu * fwv - 1) / (c->ncu * fwv);
-        if (nf > full) nf = full;
+        int nf = full;
+        if (!wide) {   /* just enough FIR waves to give every CU one workgroup */
+            nf = 1;
+            while (nf < full && (long long)c->ncu * pipe_frames(nf, false) < nframes) nf++;
+        }
         nf = env_int("QPSK_PIPE_NF", nf);
         if (nf < 1) nf = 1;
         if (nf > full) nf = full;
-        /* one lane of the serial wave per (frame, loop); record rings grow with the number of loops */
-        while (nf > 1 && (nf * fwv * nbw > 64 || pipe_lds_bytes(nf, nbw, wide) > (size_t)MAX_LDS_BYTES)) nf--;
-        if (nf * fwv * nbw > 64 || pipe_lds_bytes(nf, nbw, wide) > (size_t)MAX_LDS_BYTES)
+        while (nf > 1 && !fits(nf, wide)) nf--;
+        if (!fits(nf, wide))
             return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame, wide %d", nf, nbw, (int)wide);
         KERNEL_TRY(launch_rx_fused_pipe(a, nf, wide, c->d_status, c->stream));
     } else {
@@ -525,7 +527,7 @@ static int costas_over_symbols(qpsk_ctx *c, float *d_symbols, int nframes, int n
     a.dsrc = reinterpret_cast<const float2 *>(d_symbols);
     a.dstride = dstride;
     a.dbg = env_int("QPSK_PIPE_DBG", 0);
-    int nf = (nframes + c->ncu * pipe_frames_per_wave(false) - 1) / (c->ncu * pipe_frames_per_wave(false));
+    int nf = (nframes + c->ncu * pipe_frames(1, false) - 1) / (c->ncu * pipe_frames(1, false));
     if (nf < 1) nf = 1;
     if (nf > pipe_max_nf(false)) nf = pipe_max_nf(false);
     KERNEL_TRY(launch_costas_pipe(a, nf, c->d_status, c->stream));

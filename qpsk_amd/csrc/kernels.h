@@ -47,7 +47,7 @@ int prepare_kernels(void);
 int launch_rx_fused(const FusedArgs &a, hipStream_t s);
 /* rx_fused.hip: the producer/consumer pipeline kernel (CYCLES = 8 only) */
 size_t pipe_lds_bytes(int NF, int nbw, bool wide);
-int pipe_frames_per_wave(bool wide);   /* 4 in both geometries */
+int pipe_frames(int NF, bool wide);    /* frames of a workgroup with NF FIR waves: 4 per wave */
 int pipe_cycles(void);
 int pipe_max_nf(bool wide);            /* FIR waves per workgroup: narrow 4 (16 frames), wide 8 (32 frames) */
 int prepare_pipe_kernel(void);

@@ -68,10 +68,10 @@ constexpr int MAX_WAVES = 8;     /* FIR waves of the widest geometry */
 constexpr int SPIN_LIMIT = 1 << 24;
 
 /*
- * Two geometries of the same pipeline, chosen by the host from the batch size.  A lone wave on a SIMD issues
- * the FIR's packed multiply/add stream at ~8 cycles per instruction, two waves together at ~4 [measured: a
- * wave doing 4 frames alone and a pair doing 8 on the next SIMD finish together], so FIR throughput wants two
- * waves per SIMD, and the LDS (window + rings per frame) decides how many frames that is:
+ * Two geometries of the same pipeline, chosen by the host from the batch size.  A SIMD executes one wave's VALU
+ * instruction per 4 cycles, oldest wave first; the FIR step issues at 4.1 cycles per packed instruction from
+ * registers and 6.2 with its LDS reads (tools/ubench_fir.hip), so one FIR wave leaves a third of its SIMD idle and
+ * two saturate it.  The LDS (window + rings per frame) decides how many frames a workgroup holds:
  *   Geom<16, 4>  lane = (frame of 4) x (q of 16), 4 symbols per lane: chunks of 64 symbols, 8.6 KB of LDS per
  *                frame, 4 FIR waves = 16 frames per workgroup.  A batch of up to 16 frames per CU (config 2:
  *                4096 frames) is bounded by the recurrence, not by the FIR: the serial wave gets a SIMD of
@@ -104,7 +104,10 @@ struct Geom {
 };
 using GeomNarrow = Geom<16, 4, 4, 1, true>;
 using GeomNarrowAlt = Geom<16, 4, 4, 1, false>;  /* measurement only (QPSK_PIPE_DBG bit 4): the compiler's FIR schedule */
-using GeomWide = Geom<16, 2, 8, 0, true>;        /* spares measured worse here: 3 FIR waves on a SIMD starve the youngest */
+/* 8 FIR waves, two per SIMD, the serial wave the third on SIMD 0.  Measured and NOT kept: spare waves (3, 3, 2
+ * FIR waves per SIMD starve the youngest: 0.394 against 0.371 ms); 7 FIR waves sharing 8 frame groups in turn
+ * (no FIR wave twice on the serial wave's SIMD: 0.364 against 0.371 ms, within the run-to-run noise) */
+using GeomWide = Geom<16, 2, 8, 0, true>;
 
 #define QPSK_GEOM_CONSTANTS(GM)                                                                          \
     constexpr int QL = GM::QL, R = GM::R, FWV = GM::FWV, S = GM::S, CH = GM::CH, WSLOTS = GM::WSLOTS,    \
@@ -397,8 +400,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
      * FIR waves are hardware waves 1,2,3, 5,6,7, 9,10 (QPSK_PIPE_DBG bit 2 turns the spares off). */
     const bool spares = GM::SPARE && !(a.dbg & 4);
     const int nwaves = (int)blockDim.x / 64;
-    const int NF = spares ? (nwaves - 1) - (nwaves - 1) / 4 : nwaves - 1;
-    const int G = NF * FWV;
+    const int NF = spares ? (nwaves - 1) - (nwaves - 1) / 4 : nwaves - 1;   /* FIR waves */
+    const int G = NF * FWV;                                                 /* frames of the workgroup */
     float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));   /* [G][WSLOTS] */
     float2 *dring = win + (size_t)G * WSLOTS;                              /* [G][DSTRIDE] */
     float4 *zring = reinterpret_cast<float4 *>(dring + (size_t)G * DSTRIDE); /* [G*nbw][ZSTRIDE] records (T.x, T.y, n, -):
@@ -426,68 +429,70 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
 
     /* ======================================= FIR waves =========================================== */
     if (spares && (wave & 3) == 0) return;   /* a wave that would share a SIMD with wave 0 */
-    const int w = spares ? wave - 1 - wave / 4 : wave - 1;   /* FIR wave index */
+    const int w = spares ? wave - 1 - wave / 4 : wave - 1;   /* FIR wave index = the frame group it owns */
     const int fl = lane / QL, q = lane % QL;
-    const int g = w * FWV + fl;             /* frame slot in the workgroup */
-    const int frame = f0 + g;
-    const bool fvalid = frame < a.nframes;
 
     /* taps stay in LDS; the FIR loop keeps a rolling set of R + 1 groups of C taps in registers (broadcast reads) */
     const float4 *taps4 = reinterpret_cast<const float4 *>(sm->taps);
-
-    float2 *wf = win + (size_t)g * WSLOTS;                 /* this frame's window */
-    const float2 *rd = wf + (PAD + 1) * q;                 /* FIR read base: position PAD*q -> slot (PAD+1)*q */
-    /* write bases: loaded pair (s, s+1), s = 2*l16... one 16-byte load covers 128 samples of ONE frame, so the
-     * wave's 64 lanes sweep a frame in 4 loads; lane `lane` holds samples 2*lane, 2*lane+1 of each 128-block */
-    const float4 *src_frame[FWV];
-    int wr0[FWV], wr1[FWV];
-#pragma unroll
-    for (int ff = 0; ff < FWV; ff++) {
-        const int fr = f0 + w * FWV + ff;
-        const int ix = a.index ? (fr < a.nframes ? a.index[fr] : 0) : a.fixed_index;
-        const int p0 = 2 * lane + 126 - ix;               /* window position of sample 2*lane of the chunk */
-        wr0[ff] = (w * FWV + ff) * WSLOTS + p0 + p0 / PAD;
-        wr1[ff] = (w * FWV + ff) * WSLOTS + (p0 + 1) + (p0 + 1) / PAD;
-        src_frame[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(fr < a.nframes ? fr : 0) * L);
-    }
     constexpr int NLD = CH / 128;                          /* 16-byte loads per frame per chunk */
-    float4 pre[FWV][NLD];
+
+    /* what a wave needs to know about a frame group: one 16-byte load covers 128 samples of ONE frame, so the
+     * wave's 64 lanes sweep a frame in NLD loads; lane `lane` holds samples 2*lane, 2*lane+1 of each 128-block */
+    struct Ctx {
+        int group, g, frame;       /* group, this lane's frame slot in the workgroup, its frame */
+        bool fvalid, all_valid;
+        float2 *wf;                /* this lane's frame window */
+        const float2 *rd;          /* FIR read base: position PAD*q -> slot (PAD+1)*q */
+        int wr0[FWV], wr1[FWV];    /* window write slots of the loaded pair, per frame of the group */
+        const float4 *src[FWV];
+        bool fv[FWV];
+    };
+    auto make_ctx = [&](int group) {
+        Ctx cx;
+        cx.group = group;
+        cx.g = group * FWV + fl;
+        cx.frame = f0 + cx.g;
+        cx.fvalid = cx.frame < a.nframes;
+        cx.all_valid = f0 + group * FWV + FWV <= a.nframes;
+        cx.wf = win + (size_t)cx.g * WSLOTS;
+        cx.rd = cx.wf + (PAD + 1) * q;
+#pragma unroll
+        for (int ff = 0; ff < FWV; ff++) {
+            const int fr = f0 + group * FWV + ff;
+            cx.fv[ff] = fr < a.nframes;
+            const int ix = a.index ? (cx.fv[ff] ? a.index[fr] : 0) : a.fixed_index;   /* decimation offset, < C */
+            const int p0 = 2 * lane + 126 - ix;               /* window position of sample 2*lane of the chunk */
+            cx.wr0[ff] = (group * FWV + ff) * WSLOTS + p0 + p0 / PAD;
+            cx.wr1[ff] = (group * FWV + ff) * WSLOTS + (p0 + 1) + (p0 + 1) / PAD;
+            cx.src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(cx.fv[ff] ? fr : 0) * L);
+        }
+        return cx;
+    };
 
     /* L is even on this path (checked by the host), so a 16-byte pair is either inside the frame or past it.
      * Loads are UNCONDITIONAL (a per-load branch would make the compiler wait for each load in turn): a
-     * chunk that lies inside every frame of the wave -- all but the last one -- loads straight; the tail
+     * chunk that lies inside every frame of the group -- all but the last one -- loads straight; the tail
      * chunk clamps the address into the frame and zeroes what lies past the end afterwards. */
-    const bool wave_frames_valid = f0 + w * FWV + FWV <= a.nframes;
-    auto prefetch = [&](int c) {
-        if (wave_frames_valid && (c + 1) * CH <= L) {
+    auto prefetch = [&](const Ctx &cx, float4 (&pre)[FWV][NLD], int c) {
+        if (cx.all_valid && (c + 1) * CH <= L) {
 #pragma unroll
             for (int ff = 0; ff < FWV; ff++)
 #pragma unroll
                 for (int j = 0; j < NLD; j++)
-                    pre[ff][j] = src_frame[ff][(c * CH + 128 * j + 2 * lane) >> 1];
+                    pre[ff][j] = cx.src[ff][(c * CH + 128 * j + 2 * lane) >> 1];
         } else {
 #pragma unroll
             for (int ff = 0; ff < FWV; ff++) {
-                const bool fv = f0 + w * FWV + ff < a.nframes;
 #pragma unroll
                 for (int j = 0; j < NLD; j++) {
                     const int s = c * CH + 128 * j + 2 * lane;      /* first sample of the pair */
-                    const bool in = fv && s + 1 < L;
-                    float4 v = src_frame[ff][in ? (s >> 1) : 0];
+                    const bool in = cx.fv[ff] && s + 1 < L;
+                    float4 v = cx.src[ff][in ? (s >> 1) : 0];
                     if (!in) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     pre[ff][j] = v;
                 }
             }
         }
-    };
-
-    prefetch(0);
-    int flushed = 0;
-    bool ok = true;
-
-    auto flush_upto = [&](int upto) {
-        for (; flushed < upto; flushed++)
-            if (fvalid) flush_records<GM>(a, zring, g, frame, q, flushed);
     };
 
     /* measurement knob (QPSK_PIPE_DBG bit 5): where a FIR wave of workgroup 0 spends its shader cycles */
@@ -501,16 +506,17 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
             tlast = t;
         }
     };
-    tick(-1);
-    for (int c = 0; c < nchunks; c++) {
+
+    /* one chunk of one frame group: flush what the loop has finished with, stage the window, filter, hand over */
+    auto run_chunk = [&](const Ctx &cx, float4 (&pre)[FWV][NLD], int c, bool prefetch_next) -> bool {
         /* ring slot c % DR is free once chunk c - DR has been consumed; its outputs leave first */
         if (c >= DR) {
-            ok = wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag);
-            if (!ok) break;
+            if (!wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag)) return false;
             tick(0);
-            flush_upto(c - DR + 1);
+            if (cx.fvalid) flush_records<GM>(a, zring, cx.g, cx.frame, q, c - DR);
             tick(1);
         }
+        float2 *wf = cx.wf;
         /* history: positions [0, 126-idx) <- [CH, CH+126-idx) of the previous window (zeros for c = 0) */
         {
             constexpr int HN = 128 / QL;      /* 128 positions by the frame's QL lanes: p = q + QL*i -> slot p + p/PAD */
@@ -530,39 +536,21 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         for (int ff = 0; ff < FWV; ff++) {
 #pragma unroll
             for (int j = 0; j < NLD; j++) {
-                win[wr0[ff] + (128 + 128 / PAD) * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
-                win[wr1[ff] + (128 + 128 / PAD) * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
+                win[cx.wr0[ff] + (128 + 128 / PAD) * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
+                win[cx.wr1[ff] + (128 + 128 / PAD) * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
             }
         }
-        if (c + 1 < nchunks) prefetch(c + 1);
+        if (prefetch_next) prefetch(cx, pre, c + 1);
         tick(2);
 
         /* sliding-window FIR: symbol r of this lane uses tap k = t - C*r at window position PAD*q + t */
+        const float2 *rd = cx.rd;
         float2 acc[R];
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = (a.dbg & 1) ? make_float2(0.7f, 0.3f) : make_float2(0.0f, 0.0f);
         /* t = C*tb + u: symbol r needs tap group tb - r (taps C*(tb-r) .. +C-1), so each group of C taps is
          * live for R consecutive blocks */
         static_assert(C == 8 && (R == 4 || R == 2), "the step below is written for C = 8 and R = 2 or 4");
-        /* Software pipeline, one block of C window positions deep: the LDS reads of block tb+1 (window values
-         * and tap group) are issued before the multiply-adds of block tb.  Groups rotate through R + 1 slots so
-         * that the group fetched a block early does not overwrite the one symbol R-1 still needs. */
-        constexpr int NB = (TSTEPS + C - 1) / C;
-        float tg[R + 1][C];
-        float2 wv[2][C];
-        auto fetch_block = [&](int tb) {
-            if (tb * C < NTAPS) {
-                const float4 ta = taps4[2 * tb], tb4 = taps4[2 * tb + 1];
-                float *g_ = tg[tb % (R + 1)];
-                g_[0] = ta.x; g_[1] = ta.y; g_[2] = ta.z; g_[3] = ta.w;
-                g_[4] = tb4.x; g_[5] = tb4.y; g_[6] = tb4.z; g_[7] = tb4.w;
-            }
-#pragma unroll
-            for (int u = 0; u < C; u++) {
-                const int t = tb * C + u;
-                if (t < TSTEPS) wv[tb & 1][u] = rd[t + t / PAD];
-            }
-        };
         if constexpr (!GM::PINNED) {
             /* the compiler's own schedule of the same sum, kept for A/B runs (QPSK_PIPE_DBG bit 4): config 2
              * 0.2148 ms against 0.2088 ms with the pinned order below [measured, same process] */
@@ -590,10 +578,29 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                 }
             }
         } else if (!(a.dbg & 1)) { /* ablation knob (QPSK_PIPE_DBG bit 0): skip the filter arithmetic, keep the traffic */
-            /* Instruction order inside a step is pinned with empty asm statements (they keep their program order
+            /* Software pipeline, one block of C window positions deep: the LDS reads of block tb+1 (window values
+             * and tap group) are issued before the multiply-adds of block tb.  Groups rotate through R + 1 slots so
+             * that the group fetched a block early does not overwrite the one symbol R-1 still needs.
+             * Instruction order inside a step is pinned with empty asm statements (they keep their program order
              * and every value they name must exist where they stand): the R products of a step, then the R
              * adds.  A product is then R instructions ahead of its add and an accumulator's adds are 2R apart,
-             * more than the ~8 cycles a dependent packed op waits, so a lone wave issues back to back. */
+             * more than the ~8 cycles a dependent packed op waits. */
+            constexpr int NB = (TSTEPS + C - 1) / C;
+            float tg[R + 1][C];
+            float2 wv[2][C];
+            auto fetch_block = [&](int tb) {
+                if (tb * C < NTAPS) {
+                    const float4 ta = taps4[2 * tb], tb4 = taps4[2 * tb + 1];
+                    float *g_ = tg[tb % (R + 1)];
+                    g_[0] = ta.x; g_[1] = ta.y; g_[2] = ta.z; g_[3] = ta.w;
+                    g_[4] = tb4.x; g_[5] = tb4.y; g_[6] = tb4.z; g_[7] = tb4.w;
+                }
+#pragma unroll
+                for (int u = 0; u < C; u++) {
+                    const int t = tb * C + u;
+                    if (t < TSTEPS) wv[tb & 1][u] = rd[t + t / PAD];
+                }
+            };
             v2f ac[R];
 #pragma unroll
             for (int r = 0; r < R; r++) ac[r] = v2f{acc[r].x, acc[r].y};
@@ -639,16 +646,26 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         }
         tick(3);
         /* decimated symbols -> ring; a pick at or past the end of the block is 0 (cannot happen for idx < C) */
-        float2 *dw = dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q;
+        float2 *dw = dring + (size_t)cx.g * DSTRIDE + (c % DR) * S + R * q;
 #pragma unroll
         for (int r = 0; r < R; r++)
             dw[r] = fir_gain(acc[r]);
-        if (lane == 0) st_release(&sm->ready[w], c + 1);
+        if (lane == 0) st_release(&sm->ready[cx.group], c + 1);
         tick(4);
-    }
+        return true;
+    };
+
+    const Ctx own = make_ctx(w);
+    float4 pre[FWV][NLD];
+    prefetch(own, pre, 0);
+    bool ok = true;
+    tick(-1);
+    for (int c = 0; c < nchunks && ok; c++)
+        ok = run_chunk(own, pre, c, c + 1 < nchunks);
     if (ok) {
         ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
-        if (ok) flush_upto(nchunks);
+        if (ok && own.fvalid)
+            for (int c = max(0, nchunks - DR); c < nchunks; c++) flush_records<GM>(a, zring, own.g, own.frame, q, c);
     }
     if (!ok && lane == 0) atomicExch(status, 1);
     if (prof && lane == 0)
@@ -657,10 +674,17 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                tacc[4] / nchunks);
 }
 
+/* frames of a workgroup with NF FIR waves */
+template <class GM>
+static int frames_of(int NF)
+{
+    return NF * GM::FWV;
+}
+
 template <class GM>
 static size_t lds_bytes_of(int NF, int nbw)
 {
-    const size_t G = (size_t)NF * GM::FWV;
+    const size_t G = (size_t)frames_of<GM>(NF);
     size_t b = sizeof(Smem) + sizeof(float2) * (G * GM::WSLOTS + G * GM::DSTRIDE) + sizeof(float4) * G * nbw * GM::ZSTRIDE;
     return (b + 15) & ~(size_t)15;
 }
@@ -670,13 +694,13 @@ size_t pipe_lds_bytes(int NF, int nbw, bool wide)
     return wide ? lds_bytes_of<GeomWide>(NF, nbw) : lds_bytes_of<GeomNarrow>(NF, nbw);
 }
 
-int pipe_frames_per_wave(bool wide) { return wide ? GeomWide::FWV : GeomNarrow::FWV; }
+int pipe_frames(int NF, bool wide) { return wide ? frames_of<GeomWide>(NF) : frames_of<GeomNarrow>(NF); }
 int pipe_cycles(void) { return C; }
 int pipe_max_nf(bool wide) { return wide ? GeomWide::MAX_NF : GeomNarrow::MAX_NF; }
 
 int launch_rx_fused_pipe(const FusedArgs &a, int NF, bool wide, int *status, hipStream_t s)
 {
-    const int G = NF * pipe_frames_per_wave(wide);
+    const int G = pipe_frames(NF, wide);
     const int blocks = (a.nframes + G - 1) / G;
     const size_t lds = pipe_lds_bytes(NF, a.nbw, wide);
     if (NF < 1 || NF > pipe_max_nf(wide) || lds > (size_t)MAX_LDS_BYTES || G * a.nbw > 64) return (int)hipErrorInvalidValue;

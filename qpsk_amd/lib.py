@@ -26,7 +26,8 @@ class Params(C.Structure):
 
 
 def lib_path():
-    return os.path.join(HERE, "libqpsk_hip.so")
+    """The built library; QPSK_HIP_LIB names another build of it (A/B timing of two source versions on one box)."""
+    return os.environ.get("QPSK_HIP_LIB") or os.path.join(HERE, "libqpsk_hip.so")
 
 
 def build(verbose=False):
