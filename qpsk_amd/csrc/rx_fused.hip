@@ -495,7 +495,9 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         }
     };
 
-    /* measurement knob (QPSK_PIPE_DBG bit 5): where a FIR wave of workgroup 0 spends its shader cycles */
+    /* measurement build only (make -C qpsk_amd/csrc profile, then QPSK_PIPE_DBG bit 5): where a FIR wave of
+     * workgroup 0 spends its shader cycles.  The product library carries neither the counters nor the printf. */
+#ifdef QPSK_PIPE_PROFILE
     const bool prof = (a.dbg & 32) && blockIdx.x == 0;
     unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = 0;
     auto tick = [&](int k) {
@@ -506,6 +508,9 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
             tlast = t;
         }
     };
+#else
+    auto tick = [](int) {};
+#endif
 
     /* one chunk of one frame group: flush what the loop has finished with, stage the window, filter, hand over */
     auto run_chunk = [&](const Ctx &cx, float4 (&pre)[FWV][NLD], int c, bool prefetch_next) -> bool {
@@ -668,10 +673,12 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
             for (int c = max(0, nchunks - DR); c < nchunks; c++) flush_records<GM>(a, zring, own.g, own.frame, q, c);
     }
     if (!ok && lane == 0) atomicExch(status, 1);
+#ifdef QPSK_PIPE_PROFILE
     if (prof && lane == 0)
         printf("FIR wave %d: %d chunks; cycles per chunk: wait for the loop %llu, flush %llu, history + window %llu, filter %llu, "
                "ring hand-over %llu\n", w, nchunks, tacc[0] / nchunks, tacc[1] / nchunks, tacc[2] / nchunks, tacc[3] / nchunks,
                tacc[4] / nchunks);
+#endif
 }
 
 /* frames of a workgroup with NF FIR waves */

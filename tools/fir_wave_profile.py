@@ -1,16 +1,35 @@
-import os, sys
-sys.path.insert(0, "/root/repo")
-import torch, bench, qpsk_amd
+#!/usr/bin/env python3
+"""Measurement helper (GPU box): shader cycles per chunk that the FIR waves of workgroup 0 spend waiting for the
+Costas loop, flushing, staging the window, filtering and handing over -- both pipeline geometries.
+
+    make -C qpsk_amd/csrc profile          # in the build container: libqpsk_hip_prof.so (-DQPSK_PIPE_PROFILE)
+    python tools/fir_wave_profile.py       # on the GPU box
+
+The product library has no counters and no device printf; this script refuses to run against it."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PROF = os.path.join(ROOT, "qpsk_amd", "libqpsk_hip_prof.so")
+if not os.path.exists(PROF):
+    raise SystemExit("build the measurement library first: make -C qpsk_amd/csrc profile")
+os.environ["QPSK_HIP_LIB"] = PROF
+
+import torch  # noqa: E402
+import bench  # noqa: E402
+import qpsk_amd  # noqa: E402
+
 dev = torch.device("cuda", 0)
 for frames, tag in ((4096, "narrow"), (8192, "wide")):
     m = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=6)
     x = bench.synth_frames_gpu(torch, dev, frames, m.taps, seed=1)
     sym = torch.empty((frames, m.nsym), dtype=torch.uint8, device=dev)
-    fr = torch.empty((frames,), dtype=torch.float32, device=dev); ph = torch.empty_like(fr)
-    for dbg in (32,):
-        os.environ["QPSK_PIPE_DBG"] = str(dbg)
-        print("==== %s, QPSK_PIPE_DBG=%d" % (tag, dbg), flush=True)
-        m.rx_batch_raw(x, frames, sym, fr, ph)
-        torch.cuda.synchronize()
+    fr = torch.empty((frames,), dtype=torch.float32, device=dev)
+    ph = torch.empty_like(fr)
+    os.environ["QPSK_PIPE_DBG"] = "32"
+    print("==== %s geometry, %d frames" % (tag, frames), flush=True)
+    m.rx_batch_raw(x, frames, sym, fr, ph)
+    torch.cuda.synchronize()
     os.environ.pop("QPSK_PIPE_DBG")
     del x
