@@ -515,14 +515,22 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     /* Who turns a group's finished records into symbols.  Normally the group's own FIR wave.  In the full narrow
      * workgroup FIR waves 0 and 3 share SIMD 1 and set the pace (the younger one filters at 9.2 k cycles per
      * chunk against 6.3 k for the waves alone on SIMDs 2 and 3, which then wait ~5 k for it): there the two lone
-     * waves flush for the pair as well. */
-    const bool offload = GM::SPARE && spares && NF == 4 && !(a.dbg & 64);
-    /* (raising the younger wave's priority only swaps which of the two is late: 0.2001 against 0.1989 ms) */
-    int fgroup[2] = {w, w};
+     * waves flush for the pair as well.  (Raising the younger wave's priority only swaps which of the two is
+     * late: 0.2001 against 0.1989 ms.)  In the full wide workgroup the oldest wave of SIMDs 1-3 (FIR waves 0-2)
+     * has the slack and the younger ones, above all the two beside the serial wave, set the pace: waves 0-2 flush
+     * for everybody. */
+    const bool offload_narrow = GM::SPARE && spares && NF == 4 && !(a.dbg & 64);
+    const bool offload_wide = !GM::SPARE && NF == 8 && !(a.dbg & 64);
+    int fgroup[3] = {w, w, w};
     int nflush = 1;
-    if (offload) {
+    if (offload_narrow) {
         if (w == 1) { nflush = 2; fgroup[1] = 3; }
         else if (w == 2) { nflush = 2; fgroup[1] = 0; }
+        else nflush = 0;
+    } else if (offload_wide) {
+        if (w == 0) { nflush = 3; fgroup[1] = 4; fgroup[2] = 7; }
+        else if (w == 1) { nflush = 3; fgroup[1] = 5; fgroup[2] = 3; }
+        else if (w == 2) { nflush = 2; fgroup[1] = 6; }
         else nflush = 0;
     }
     auto flush_chunk = [&](int chunk) {
