@@ -36,20 +36,34 @@ def test_headers_compile_as_c11(tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
 
 
-def build_c_example(out_dir):
-    """examples/loopback.c: a C11 host that uses nothing but include/qpsk_hip.h and the shared library"""
+def build_c_example(out_dir, name="loopback"):
+    """examples/<name>.c: a C11 host that uses nothing but include/*.h and the shared library"""
     import subprocess
     import qpsk_amd
-    exe = os.path.join(str(out_dir), "loopback")
+    exe = os.path.join(str(out_dir), name)
     libdir = os.path.dirname(qpsk_amd.lib_path())
     subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "loopback.c"), "-L", libdir, "-lqpsk_hip",
+                           os.path.join(ROOT, "examples", name + ".c"), "-L", libdir, "-lqpsk_hip", "-lm",
                            "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
 
-def test_c_host_example_builds_and_links(qpsk_lib, tmp_path):
-    assert os.path.exists(build_c_example(tmp_path))
+@pytest.mark.parametrize("name", ["loopback", "dropin_main"])
+def test_c_host_example_builds_and_links(qpsk_lib, tmp_path, name):
+    assert os.path.exists(build_c_example(tmp_path, name))
+
+
+@pytest.mark.gpu
+def test_c_dropin_main_tracks_the_transmitter_offset(qpsk_lib, tmp_path):
+    """the reference's main() loop (qpsk.c:289-359) against include/qpsk_dropin.h, shipped parameters: rx_frame()
+    block by block on PCM from a transmitter 50 Hz off centre; the loop's estimate settles there (the oracle fed the
+    same way reads 49.9-50.0 Hz after 50 blocks)"""
+    import subprocess
+    exe = build_c_example(tmp_path, "dropin_main")
+    r = subprocess.run([exe, "200"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    hz = float(r.stdout.rsplit("final offset estimate", 1)[1].split()[0])
+    assert abs(hz - 50.0) < 1.0, r.stdout
 
 
 @pytest.mark.gpu
