@@ -3,39 +3,49 @@
  * instruction stream, for the serial wave of rx_fused_pipe_kernel.
  *
  * Why assembly: the recurrence runs in ONE wave per workgroup and that wave is strictly in order.  Measured
- * on MI355X (tools/ubench.hip, tools/gen_ubench_costas.py): a lone wave issues one VALU instruction per ~5
- * cycles and a dependent one ~8 cycles after its producer; every LDS instruction costs the wave ~12 cycles
- * of issue; a branch that waits for a VALU compare, or a TAKEN branch, stalls it for tens of cycles.  A step
- * is a chain of ~19 dependent operations (phase -> range reduction -> cosine Horner chain -> rotate ->
- * detector -> loop update -> phase); the compiler's version of it ran ~355 cycles per step, the arithmetic
- * chain alone is ~140.  What this stream does about it:
- *   - off-chain work is slotted between the dependent operations;
+ * on MI355X with timing-only variants of this stream inside the kernel: the lone wave issues
+ * one VALU instruction per ~5.2 cycles -- the step is ISSUE bound, an instruction more or less is ~5.5 cycles,
+ * while taking dependent fp32 operations off the critical path changes nothing; only the five fp64 operations
+ * phase -> range reduction -> x^2, each waiting ~8 cycles for the one before, leave issue slots empty.  Every
+ * LDS instruction costs the wave 12-14 cycles of issue, a not-taken branch on a VALU compare ~10.  The
+ * compiler's version of the step ran ~355 cycles.  What this stream does about it:
+ *   - 28 VALU instructions per step;
+ *   - the tail of step k that nothing in step k+1 waits for -- its record write, the frequency clamp, the
+ *     exact-zero test, the 2*pi test -- is issued in the empty slots of step k+1's fp64 head;
+ *   - the 2*pi wrap is out of line AND late: step k+1 starts from the unwrapped phase, the branch sits four
+ *     instructions after its compare, and the rare wrap block corrects the phase and redoes the head;
  *   - LDS traffic is 1.5 instructions per step: two symbols per ds_read_b128 (fetched two steps ahead into
  *     alternating register sets), one 16-byte record (T.x, T.y, n, -) per ds_write_b128;
- *   - the 2*pi wrap is out of line: the common case falls through one not-taken branch whose compare was
- *     issued several instructions earlier; the wrap block fixes the phase and jumps back;
- *   - the exact-zero test of the detector input is a running min over a group of 8 steps; with zeros out of
- *     the way sgn(T.x) T.y is |T.y| carrying the sign of T.x ^ T.y (one xor, two bit-field inserts, no compares).
+ *   - groups of 16 steps: the per-group bookkeeping (state snapshot, flag test, taken loop branch) costs
+ *     ~60 cycles;
+ *   - the exact-zero test of the detector input is a running min over the group; with zeros out of the way
+ *     the error is e = s (|T.y| - |T.x|) with s = sgn(T.x) sgn(T.y) (negating both operands of a float
+ *     subtraction negates its result), so d = |T.y| - |T.x| is one subtract with abs modifiers and s rejoins it
+ *     as the +-1.0f factor of the two fused multiply-adds that update freq and phase (+-1 x float is exact, so
+ *     each is the reference's unfused multiply, then add).  Only the sign of a ZERO error differs (s d = -0
+ *     where the reference has +0), and that is visible only when freq is -0; freq can be -0 only as loaded
+ *     state (costas_loop.c:56: x + y = -0 needs both -0, and beta e = -0 needs T = 0, which is flagged), so
+ *     the caller keeps a group that starts with freq = -0 away from this stream.
  *
- * Arithmetic = costas_step_t() in qpsk_device.h operation for operation: Horner sin/cos polynomials in fp64
- * with fused multiply-adds (the library's form), everything in fp32 unfused (the reference is built without
- * contraction), the 2*pi wrap in fp64 (costas_loop.c:61-67), the clamp as a median of 3 (callers use this
- * stream only when min_freq < 0 < max_freq, where it equals costas_loop.c:69-74).  The parity tests compare
- * the kernel with the oracle bit for bit.
+ * Arithmetic = costas_step_t() in qpsk_device.h: Horner sin/cos polynomials in fp64 with fused multiply-adds
+ * (the library's form), everything else in fp32 unfused (the reference is built without contraction), the
+ * 2*pi wrap in fp64 (costas_loop.c:61-67), the clamp as a median of 3 (callers use this stream only when
+ * min_freq < 0 < max_freq, where it equals costas_loop.c:69-74).  The parity tests compare the kernel with
+ * the oracle bit for bit.
  *
- * One call runs `groups` groups of 8 steps; the first symbol must be an EVEN one (16-byte aligned pairs).
- * Cases the stream does not handle set a flag, and the group they occur in is abandoned with the loop state
- * restored to the group's start; the caller redoes that group with costas_step_t() and continues:
+ * One call runs `groups` groups of COSTAS_ASM_GROUP steps; the first symbol must be an EVEN one (16-byte
+ * aligned pairs).  Cases the stream does not handle set a flag, and the group they occur in is abandoned with
+ * the loop state restored to the group's start; the caller redoes that group with costas_step_t() and continues:
  *     min(|T.x|, |T.y|) == 0   (the detector's sgn(0) = -1 asymmetry, see costas_step_t)
  *     a phase still outside [-2pi, 2pi] after ONE wrap (clamp wider than +-2pi, huge amplitudes).
  *
- * Registers: v[100:139] (136:139 = the second pair of decimated symbols) are scratch owned by the block (clobbered; low enough for a kernel built for three
+ * Registers: v[100:139] are scratch owned by the block (clobbered; low enough for a kernel built for three
  * waves per SIMD, i.e. at most 168 VGPRs):
- *   100:101 x / d*C      102:103 beta*e, alpha*e   104:105 n / x3 / d*S     106:107 xr / e
- *   108:109 x2 / a, b    110:111 cos chain (v110 = C)   112:113 sin chain (v112 = S)
+ *   100:101 x / d*C      102:103 beta*d, alpha*d   104:105 n / x3 / d*S     106:107 xr / d
+ *   108:109 x2 / s       110:111 cos chain (v110 = C)   112:113 sin chain (v112 = S)
  *   114:117 the record: T.x, T.y, then the magic sum (v116 bits 1:0 = quadrant, v117 don't care)
- *   118 f2   119 p+f2    120:123 two decimated symbols   126 running min   127 2pi hi   128:129 +-2pi
- *   130,131 group-start phase/freq    132..135 phase/freq ping-pong
+ *   118 f2   119 p+f2    120:123, 136:139 two pairs of decimated symbols   126 running min
+ *   127 2pi hi   128:129 +-2pi   130,131 group-start phase/freq    132..135 phase/freq ping-pong
  */
 #ifndef QPSK_COSTAS_ASM_H
 #define QPSK_COSTAS_ASM_H
@@ -43,6 +53,9 @@
 #include "qpsk_device.h"
 
 namespace qpsk {
+
+/* steps per group of the stream; the caller hands over multiples of it */
+constexpr int COSTAS_ASM_GROUP = 16;
 
 /* 32-bit LDS byte address of a __shared__ object (what ds_read / ds_write take) */
 __device__ __forceinline__ unsigned lds_addr(const void *p)
@@ -53,17 +66,39 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 #define QPSK_STR_(x) #x
 #define QPSK_STR(x) QPSK_STR_(x)
 
-/*
- * one step: PIN/FIN -> POUT/FOUT.  DREG = the VGPR pair holding this step's symbol, WAIT = the lgkmcnt wait
- * in front of its first use, READ = the LDS fetch of the next pair (odd steps) or nothing, ZOFF = byte offset
- * of this step's record, LW/LR = the out-of-line wrap block's label and its return label.
- */
-#define QPSK_COSTAS_STEP(PIN, FIN, POUT, FOUT, DREG, WAIT, READ, ZOFF, LW, LR)                                \
+/* head of a step: phase PIN -> n (v116 low bits), xr = PIN - n pi/2 (v106:107), xr^2 (v108:109) */
+#define QPSK_HEAD_CHAIN(PIN)                                                                                  \
     "v_cvt_f64_f32 v[100:101], " PIN "\n\t"                                                                   \
     "v_fma_f64 v[116:117], v[100:101], %[k2pi], %[magic]\n\t"                                                 \
     "v_add_f64 v[104:105], v[116:117], -%[magic]\n\t"                                                         \
     "v_fma_f64 v[106:107], -v[104:105], %[hpi], v[100:101]\n\t"                                               \
-    "v_mul_f64 v[108:109], v[106:107], v[106:107]\n\t"                                                        \
+    "v_mul_f64 v[108:109], v[106:107], v[106:107]\n\t"
+
+/*
+ * the same head with the previous step's leftovers in its empty issue slots: that step's record (offset ZPREV),
+ * its clamped frequency (-> FIN, this step's input), its exact-zero test, and the 2*pi test of its phase PIN.
+ * The head runs on the unwrapped PIN; LW (QPSK_WRAP_HEAD) wraps PIN in place, redoes the head, returns to LR.
+ */
+#define QPSK_HEAD_DEFERRED(PIN, FIN, ZPREV, LW, LR)                                                           \
+    "v_cvt_f64_f32 v[100:101], " PIN "\n\t"                                                                   \
+    "ds_write_b128 %[za], v[114:117] offset:" QPSK_STR(ZPREV) "\n\t"                                          \
+    "v_cmp_ge_f32_e64 vcc, |" PIN "|, %[tau]\n\t"                                                             \
+    "v_fma_f64 v[116:117], v[100:101], %[k2pi], %[magic]\n\t"                                                 \
+    "v_med3_f32 " FIN ", v118, %[fmin], %[fmax]\n\t"                                                          \
+    "v_add_f64 v[104:105], v[116:117], -%[magic]\n\t"                                                         \
+    "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
+    "v_fma_f64 v[106:107], -v[104:105], %[hpi], v[100:101]\n\t"                                               \
+    "s_cbranch_vccnz " LW "f\n\t"                                                                             \
+    "v_mul_f64 v[108:109], v[106:107], v[106:107]\n"                                                          \
+    LR ":\n\t"
+
+/*
+ * the rest of a step: sin/cos polynomials -> T = symbol x conj(C + jS) -> detector -> loop update.  Leaves
+ * T in v114:115 (with v116 from the head: the record), the unclamped frequency in v118, the new phase,
+ * unwrapped, in POUT.  DREG = the VGPR pair holding this step's symbol, WAIT = the lgkmcnt wait in front of
+ * its first use, READ = the LDS fetch of the pair after next (even steps) or nothing.
+ */
+#define QPSK_BODY(PIN, FIN, POUT, DREG, WAIT, READ)                                                           \
     "v_fma_f64 v[110:111], v[108:109], %[c4], %[c3]\n\t"                                                      \
     "v_fma_f64 v[112:113], v[108:109], %[s3], %[s2]\n\t"                                                      \
     "v_fma_f64 v[110:111], v[108:109], v[110:111], %[c2]\n\t"                                                 \
@@ -79,31 +114,44 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     "v_pk_mul_f32 v[104:105], " DREG ", v[112:113] op_sel:[1,0] op_sel_hi:[0,0]\n\t"                          \
     READ                                                                                                      \
     "v_pk_add_f32 v[114:115], v[100:101], v[104:105] neg_hi:[0,1]\n\t"                                        \
-    "v_xor_b32_e32 v108, v114, v115\n\t"                      /* sign bit = sgn(T.x) sgn(T.y) (no zeros: v126) */ \
-    "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
-    "v_bfi_b32 v109, %[absm], v115, v108\n\t"                 /* sgn(T.x) T.y = |T.y| with that sign */          \
-    "v_bfi_b32 v108, %[absm], v114, v108\n\t"                 /* sgn(T.y) T.x */                                  \
-    "v_sub_f32_e32 v106, v109, v108\n\t"                                                                      \
-    "v_pk_mul_f32 v[102:103], %[beal], v[106:107] op_sel_hi:[1,0]\n\t"                                        \
-    "v_add_f32_e32 v118, " FIN ", v102\n\t"                                                                   \
+    "v_sub_f32_e64 v106, |v115|, |v114|\n\t"                  /* d = |T.y| - |T.x|;  e = s d */                  \
+    "v_xor_b32_e32 v108, v114, v115\n\t"                      /* sign bit of s = sgn(T.x) sgn(T.y) */            \
+    "v_pk_mul_f32 v[102:103], %[beal], v[106:107] op_sel_hi:[1,0]\n\t"   /* (beta d, alpha d) */                \
+    "v_bfi_b32 v108, %[absm], 1.0, v108\n\t"                  /* s as +-1.0f */                                  \
+    "v_fma_f32 v118, v108, v102, " FIN "\n\t"                 /* freq + beta e */                                \
     "v_add_f32_e32 v119, " PIN ", v118\n\t"                                                                   \
-    "v_add_f32_e32 " POUT ", v119, v103\n\t"                                                                  \
+    "v_fma_f32 " POUT ", v108, v103, v119\n\t"                /* (phase + freq) + alpha e */
+
+/* the leftovers of a group's LAST step, in line: record at ZOFF, clamp -> FOUT, zero test, 2*pi test of POUT */
+#define QPSK_TAIL(POUT, FOUT, ZOFF, LW, LR)                                                                   \
     "v_cmp_ge_f32_e64 vcc, |" POUT "|, %[tau]\n\t"                                                            \
     "ds_write_b128 %[za], v[114:117] offset:" QPSK_STR(ZOFF) "\n\t"                                           \
     "v_med3_f32 " FOUT ", v118, %[fmin], %[fmax]\n\t"                                                         \
+    "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
     "s_cbranch_vccnz " LW "f\n"                                                                               \
     LR ":\n\t"
 
-/* the out-of-line wrap of costas_loop.c:61-67 for one step: phase -= copysign(2pi, phase) in fp64, once */
-#define QPSK_COSTAS_WRAP(POUT, LW, LR)                                                                        \
-    LW ":\n\t"                                                                                                \
-    "v_cvt_f64_f32 v[100:101], " POUT "\n\t"                                                                  \
-    "v_bfi_b32 v129, %[absm], v127, " POUT "\n\t"                                                             \
+/* costas_loop.c:61-67 for the lanes in vcc: P -= copysign(2pi, P) in fp64, once; still outside -> flag */
+#define QPSK_WRAP_ONCE(P)                                                                                     \
+    "v_bfi_b32 v129, %[absm], v127, " P "\n\t"                                                                \
     "v_add_f64 v[100:101], v[100:101], -v[128:129]\n\t"                                                       \
     "v_cvt_f32_f64 v104, v[100:101]\n\t"                                                                      \
-    "v_cndmask_b32_e32 " POUT ", " POUT ", v104, vcc\n\t"                                                     \
-    "v_cmp_ge_f32_e64 vcc, |" POUT "|, %[tau]\n\t"                                                            \
-    "s_or_b64 %[fl], %[fl], vcc\n\t"                                                                          \
+    "v_cndmask_b32_e32 " P ", " P ", v104, vcc\n\t"                                                           \
+    "v_cmp_ge_f32_e64 vcc, |" P "|, %[tau]\n\t"                                                               \
+    "s_or_b64 %[fl], %[fl], vcc\n\t"
+
+/* out-of-line wrap for QPSK_HEAD_DEFERRED: v[100:101] still holds (double)PIN; wrap, then the head again */
+#define QPSK_WRAP_HEAD(PIN, LW, LR)                                                                           \
+    LW ":\n\t"                                                                                                \
+    QPSK_WRAP_ONCE(PIN)                                                                                       \
+    QPSK_HEAD_CHAIN(PIN)                                                                                      \
+    "s_branch " LR "b\n"
+
+/* out-of-line wrap for QPSK_TAIL */
+#define QPSK_WRAP_TAIL(POUT, LW, LR)                                                                          \
+    LW ":\n\t"                                                                                                \
+    "v_cvt_f64_f32 v[100:101], " POUT "\n\t"                                                                  \
+    QPSK_WRAP_ONCE(POUT)                                                                                      \
     "s_branch " LR "b\n"
 
 /* symbol pairs alternate between two register sets, each fetched TWO steps before its first use (the FIR waves
@@ -113,11 +161,20 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 #define QPSK_RDA(OFF) "ds_read_b128 v[120:123], %[da] offset:" QPSK_STR(OFF) "\n\t"
 #define QPSK_RDB(OFF) "ds_read_b128 v[136:139], %[da] offset:" QPSK_STR(OFF) "\n\t"
 
+/* steps 1..14 of a group come in pairs (odd, even): phase/freq v132,v133 -> v134,v135 -> v132,v133; Z_O/Z_E =
+ * record offsets of the steps BEFORE the odd and the even one, LO_O/LO_E their symbol registers, RD the fetch the
+ * even step issues */
+#define QPSK_STEP_PAIR(Z_O, Z_E, LO_O, LO_E, RD, LW1, LR1, LW2, LR2)                                          \
+    QPSK_HEAD_DEFERRED("v132", "v133", Z_O, LW1, LR1)                                                         \
+    QPSK_BODY("v132", "v133", "v134", LO_O, "", "")                                                           \
+    QPSK_HEAD_DEFERRED("v134", "v135", Z_E, LW2, LR2)                                                         \
+    QPSK_BODY("v134", "v135", "v132", LO_E, QPSK_WAIT2, RD)
+
 /*
- * Runs up to `groups` groups of 8 steps starting at LDS addresses d_addr (symbols, 8 bytes each, 16-byte
- * aligned) and z_addr (records, 16 bytes each); both are advanced on return.  Returns the number of groups
- * NOT done: 0, or -- if the flag word is nonzero -- the abandoned group and everything after it, with
- * phase/freq restored to that group's start.
+ * Runs up to `groups` groups of COSTAS_ASM_GROUP steps starting at LDS addresses d_addr (symbols, 8 bytes each,
+ * 16-byte aligned) and z_addr (records, 16 bytes each); both are advanced on return.  Returns the number of
+ * groups NOT done: 0, or -- if the flag word is nonzero -- the abandoned group and everything after it, with
+ * phase/freq restored to that group's start.  freq must not be -0.0f (see the header).
  */
 __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, unsigned &d_addr, unsigned &z_addr,
                                                    unsigned groups, float alpha, float beta, float min_freq,
@@ -125,7 +182,7 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
 {
     unsigned long long flags, tmp;
     const double magic = 0x1.8p52, c3 = -0x1.6c087e89a359dp-10, s2 = 0x1.1107605230bc4p-7;
-    double beal;                 /* (beta, alpha) as one VGPR pair for the packed multiply by e */
+    double beal;                 /* (beta, alpha) as one VGPR pair for the packed multiply by d */
     {
         const float2 ba = make_float2(beta, alpha);
         __builtin_memcpy(&beal, &ba, 8);
@@ -140,20 +197,27 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         "v_mov_b32 v130, %[p]\n\t"
         "v_mov_b32 v131, %[f]\n\t"
         "v_mov_b32 v126, 0x7f800000\n\t"        /* running min of |T.x|, |T.y| over the group: 0 <=> some exact zero */
-        QPSK_COSTAS_STEP("%[p]", "%[f]", "v132", "v133", "v[120:121]", QPSK_WAIT2, QPSK_RDB(16), 0, "10", "20")
-        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", "", 16, "11", "21")
-        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[136:137]", QPSK_WAIT2, QPSK_RDA(32), 32, "12", "22")
-        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[138:139]", "", "", 48, "13", "23")
-        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[120:121]", QPSK_WAIT2, QPSK_RDB(48), 64, "14", "24")
-        QPSK_COSTAS_STEP("v132", "v133", "v134", "v135", "v[122:123]", "", "", 80, "15", "25")
-        QPSK_COSTAS_STEP("v134", "v135", "v132", "v133", "v[136:137]", QPSK_WAIT2, QPSK_RDA(64), 96, "16", "26")
-        QPSK_COSTAS_STEP("v132", "v133", "%[p]", "%[f]", "v[138:139]", "", "", 112, "17", "27")
+        /* step 0 */
+        QPSK_HEAD_CHAIN("%[p]")
+        QPSK_BODY("%[p]", "%[f]", "v132", "v[120:121]", QPSK_WAIT2, QPSK_RDB(16))
+        /* steps 1..14 */
+        QPSK_STEP_PAIR(0, 16, "v[122:123]", "v[136:137]", QPSK_RDA(32), "101", "201", "102", "202")
+        QPSK_STEP_PAIR(32, 48, "v[138:139]", "v[120:121]", QPSK_RDB(48), "103", "203", "104", "204")
+        QPSK_STEP_PAIR(64, 80, "v[122:123]", "v[136:137]", QPSK_RDA(64), "105", "205", "106", "206")
+        QPSK_STEP_PAIR(96, 112, "v[138:139]", "v[120:121]", QPSK_RDB(80), "107", "207", "108", "208")
+        QPSK_STEP_PAIR(128, 144, "v[122:123]", "v[136:137]", QPSK_RDA(96), "109", "209", "110", "210")
+        QPSK_STEP_PAIR(160, 176, "v[138:139]", "v[120:121]", QPSK_RDB(112), "111", "211", "112", "212")
+        QPSK_STEP_PAIR(192, 208, "v[122:123]", "v[136:137]", QPSK_RDA(128), "113", "213", "114", "214")
+        /* step 15 and its own leftovers */
+        QPSK_HEAD_DEFERRED("v132", "v133", 224, "115", "215")
+        QPSK_BODY("v132", "v133", "%[p]", "v[138:139]", "", "")
+        QPSK_TAIL("%[p]", "%[f]", 240, "116", "216")
         "v_cmp_eq_f32_e64 %[tm], 0, v126\n\t"
         "s_or_b64 %[fl], %[fl], %[tm]\n\t"
         "s_cmp_lg_u64 %[fl], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
-        "v_add_u32_e32 %[da], 64, %[da]\n\t"
-        "v_add_u32_e32 %[za], 0x80, %[za]\n\t"
+        "v_add_u32_e32 %[da], 0x80, %[da]\n\t"
+        "v_add_u32_e32 %[za], 0x100, %[za]\n\t"
         "s_sub_u32 %[ng], %[ng], 1\n\t"
         "s_cmp_lg_u32 %[ng], 0\n\t"
         "s_cbranch_scc1 2b\n\t"
@@ -162,14 +226,22 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         "v_mov_b32 %[p], v130\n\t"
         "v_mov_b32 %[f], v131\n\t"
         "s_branch 4f\n"
-        QPSK_COSTAS_WRAP("v132", "10", "20")
-        QPSK_COSTAS_WRAP("v134", "11", "21")
-        QPSK_COSTAS_WRAP("v132", "12", "22")
-        QPSK_COSTAS_WRAP("v134", "13", "23")
-        QPSK_COSTAS_WRAP("v132", "14", "24")
-        QPSK_COSTAS_WRAP("v134", "15", "25")
-        QPSK_COSTAS_WRAP("v132", "16", "26")
-        QPSK_COSTAS_WRAP("%[p]", "17", "27")
+        QPSK_WRAP_HEAD("v132", "101", "201")
+        QPSK_WRAP_HEAD("v134", "102", "202")
+        QPSK_WRAP_HEAD("v132", "103", "203")
+        QPSK_WRAP_HEAD("v134", "104", "204")
+        QPSK_WRAP_HEAD("v132", "105", "205")
+        QPSK_WRAP_HEAD("v134", "106", "206")
+        QPSK_WRAP_HEAD("v132", "107", "207")
+        QPSK_WRAP_HEAD("v134", "108", "208")
+        QPSK_WRAP_HEAD("v132", "109", "209")
+        QPSK_WRAP_HEAD("v134", "110", "210")
+        QPSK_WRAP_HEAD("v132", "111", "211")
+        QPSK_WRAP_HEAD("v134", "112", "212")
+        QPSK_WRAP_HEAD("v132", "113", "213")
+        QPSK_WRAP_HEAD("v134", "114", "214")
+        QPSK_WRAP_HEAD("v132", "115", "215")
+        QPSK_WRAP_TAIL("%[p]", "116", "216")
         "4:\n\t"
         "s_waitcnt lgkmcnt(0)"
         : [p] "+v"(phase), [f] "+v"(freq), [da] "+v"(d_addr), [za] "+v"(z_addr), [ng] "+s"(groups),

@@ -216,16 +216,20 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
              * the LDS pipe (which the FIR waves keep busy); reading one slot past the chunk is harmless
              * (next slot or the row's padding element) */
             if (fast_clamp && !(a.dbg & 8)) {
-                /* groups of 8 steps in the hand-scheduled stream (costas_asm.h); a group it abandons
-                 * (exact-zero detector input, double wrap) is redone here with the C++ step */
-                while (cnt - j >= 8) {
+                /* groups of steps in the hand-scheduled stream (costas_asm.h); a group it abandons (exact-zero
+                 * detector input, double wrap) is redone here with the C++ step, and so is one that would start
+                 * with freq = -0 (loaded state only), where the stream's zero error has the wrong sign */
+                constexpr int AG = COSTAS_ASM_GROUP;
+                while (cnt - j >= AG) {
                     unsigned da = lds_addr(dl + slot + j), za = lds_addr(zl + slot + j);
                     unsigned long long fl;
-                    const unsigned want = __builtin_amdgcn_readfirstlane((unsigned)(cnt - j) / 8);   /* wave-uniform */
-                    const unsigned left = costas_asm_run(ph, fr, da, za, want, al, be, fmin_, fmax_, fl);
-                    j += 8 * (int)(want - left);
+                    const unsigned want = __builtin_amdgcn_readfirstlane((unsigned)(cnt - j) / AG);   /* wave-uniform */
+                    unsigned left = want;
+                    if (!__any(__float_as_uint(fr) == 0x80000000u))
+                        left = costas_asm_run(ph, fr, da, za, want, al, be, fmin_, fmax_, fl);
+                    j += AG * (int)(want - left);
                     if (left != 0) {
-                        for (int i = 0; i < 8; i++, j++) {
+                        for (int i = 0; i < AG; i++, j++) {
                             float tx, ty; unsigned qq;
                             costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
                             zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);

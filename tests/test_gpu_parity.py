@@ -435,6 +435,46 @@ def test_costas_batch_with_state(oracle):
         assert bits_equal(cpu(st[f]), np.array([c.phase, c.freq], np.float32))
 
 
+def test_costas_zero_error_and_signed_zero_state(oracle):
+    """|T.x| == |T.y| makes the detector's error an exact zero whose SIGN reaches freq and phase when those are -0
+    (costas_loop.c:44-59: -0 + +0 = +0); the hand-scheduled stream carries |T.y| - |T.x| and a +-1 factor instead,
+    so these steps must take its exact fallback.  Symbols on the diagonals with the loop at phase -0, alone and
+    scattered among random ones."""
+    import torch
+    from oracle.pyoracle import Costas
+    m = modem(fs=19200.0, rs=2400.0, frame_size=1024)
+    rng = np.random.default_rng(11)
+    F, N = 24, 128
+    d = rng.standard_normal((F, N, 2)).astype(np.float32)
+    diag = rng.uniform(.25, 2, (F, N)).astype(np.float32)
+    sx = rng.choice(np.float32([-1, 1]), (F, N))
+    sy = rng.choice(np.float32([-1, 1]), (F, N))
+    on_diag = np.zeros((F, N), bool)
+    on_diag[:8] = True                                   # whole frames: the loop never leaves phase -0
+    on_diag[8:16, :17] = True                            # a run at the start, then random symbols
+    on_diag[16:] = rng.random((F - 16, N)) < .1
+    d[on_diag, 0] = (diag * sx)[on_diag]
+    d[on_diag, 1] = (diag * sy)[on_diag]
+    st0 = np.zeros((F, 2), np.float32)
+    st0[0::2] = [-0.0, -0.0]
+    st0[1::4] = [-0.0, 0.0]
+    st = torch.from_numpy(st0.copy()).cuda()
+    sym, z = m.costas(d, st)
+    m.sync()
+    for f in range(F):
+        c = Costas()
+        oracle.lib.qo_costas_create(C.byref(c), BW, -1.0, 1.0)
+        c.phase, c.freq = float(st0[f, 0]), float(st0[f, 1])
+        zr, zi = C.c_float(), C.c_float()
+        want = np.empty((N, 2), np.float32)
+        for i in range(N):
+            s = oracle.lib.qo_costas_step(C.byref(c), float(d[f, i, 0]), float(d[f, i, 1]), C.byref(zr), C.byref(zi))
+            assert s == int(sym[f, i]), (f, i)
+            want[i] = zr.value, zi.value
+        assert bits_equal(cpu(z[f]), want), f
+        assert bits_equal(cpu(st[f]), np.array([c.phase, c.freq], np.float32)), (f, cpu(st[f]), c.phase, c.freq)
+
+
 def test_fft_batch(oracle):
     rng = np.random.default_rng(4)
     m = modem()

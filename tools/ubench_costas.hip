@@ -27,10 +27,10 @@ __global__ void k(const float2 *din, int nsym, float alpha, float beta, unsigned
             if (!usecpp) {
                 unsigned da = lds_addr(d + lane * 66), za = lds_addr(z + lane * 65);
                 unsigned long long fl;
-                unsigned left = 8;
+                unsigned left = 64 / COSTAS_ASM_GROUP;
                 while (left) {
                     left = costas_asm_run(ph, fr, da, za, __builtin_amdgcn_readfirstlane(left), alpha, beta, -1.0f, 1.0f, fl);
-                    if (left) { da += 64; za += 128; left--; }   // skip a flagged group (timing only)
+                    if (left) { da += 8 * COSTAS_ASM_GROUP; za += 16 * COSTAS_ASM_GROUP; left--; }   // skip a flagged group (timing only)
                 }
             } else {
                 for (int j = 0; j < 64; j++) {
