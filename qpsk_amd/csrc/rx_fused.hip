@@ -95,12 +95,17 @@ struct Geom {
     static constexpr int PAD = R * C;        /* lanes of a frame are PAD positions apart: position p lives at slot p + p/PAD */
     static constexpr int WL = CH + 128;      /* window positions kept per frame */
     /* padded; frame stride = 16 (mod 32) slots: the two frames of a 32-lane LDS pass use complementary banks */
-    static constexpr int WSLOTS = ((WL + WL / PAD + 1 + 31) / 32) * 32 + 16;
+    static constexpr int WSLOTS = ((WL + WL / (2 * C) + 1 + 31) / 32) * 32 + 16;   /* room for the tightest padding used: 2-symbol lanes */
     static constexpr int DSTRIDE = DR * S + 2;   /* float2 slots per frame row: 16-byte aligned rows (the Costas wave reads two
                                                     symbols per ds_read_b128), 4 dwords (mod 64) apart: lanes hit different bank quads */
     static constexpr int ZSTRIDE = DR * S + 1;   /* 16-byte records (T.x, T.y, n, -) per Costas row */
-    static constexpr int MAX_THREADS = 64 * (MAX_NF + 1 + SPARE * ((MAX_NF - 1) / 3));
+    static constexpr int MAX_THREADS = SPARE ? 512 : 64 * (MAX_NF + 1);   /* with spares: 3 + 2 FIR waves, 3 retiring ones */
     static_assert(QL == 16 && 64 % QL == 0 && 128 % PAD == 0, "slot arithmetic assumes 16 lanes per frame");
+};
+/* lane mapping of one FIR wave: QL lanes per frame, R symbols per lane */
+template <int QL_, int R_>
+struct WaveMap {
+    static constexpr int QL = QL_, R = R_;
 };
 using GeomNarrow = Geom<16, 4, 4, 1, true>;
 using GeomNarrowAlt = Geom<16, 4, 4, 1, false>;  /* measurement only (QPSK_PIPE_DBG bit 4): the compiler's FIR schedule */
@@ -181,7 +186,9 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
             st.freq = a.state_in[2 * ((size_t)(f0 + g) * nbw + b) + 1];
         }
     }
-    const int gw = (lane < G * nbw ? g : 0) / FWV;       /* the FIR wave that feeds this lane */
+    /* the FIR wave that feeds this lane: 4 frames each; in the mixed workgroup frames 12..15 come two per wave */
+    const int gl = lane < G * nbw ? g : 0;
+    const int gw = a.mixed && gl >= 12 ? 3 + (gl - 12) / 2 : gl / FWV;
     const float2 *dl = dring + (size_t)(lane < G * nbw ? g : 0) * DSTRIDE;
     float4 *zl = zring + (size_t)lane * ZSTRIDE;
     /* one median-of-3 instead of two compare/select pairs when the clamp is the usual min < 0 < max */
@@ -276,10 +283,11 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
  * record (T, n) -> z = T (-j)^(n&3) = costas_frame[] (qpsk.c:197), slicer (qpsk.c:74-79), 4 symbols per
  * 32-bit store.
  */
-template <class GM>
+template <class GM, int RW = GM::R>   /* RW symbols per lane: S / RW lanes per frame */
 __device__ __forceinline__ void flush_records(const FusedArgs &a, const float4 *zring, int g, int frame, int q, int chunk)
 {
-    QPSK_GEOM_CONSTANTS(GM);
+    constexpr int R = RW, S = GM::S, ZSTRIDE = GM::ZSTRIDE;
+    static_assert(R == 2 || R == 4, "packs 2 or 4 symbols per store");
     const int nbw = a.nbw, N = a.nsym;
     const int slot = (chunk % DR) * S, sym0 = chunk * S;
     const int cnt = min(S, N - sym0);
@@ -404,7 +412,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
      * FIR waves are hardware waves 1,2,3, 5,6,7, 9,10 (QPSK_PIPE_DBG bit 2 turns the spares off). */
     const bool spares = GM::SPARE && !(a.dbg & 4);
     const int nwaves = (int)blockDim.x / 64;
-    const int NF = spares ? (nwaves - 1) - (nwaves - 1) / 4 : nwaves - 1;   /* FIR waves */
+    const bool mixed = a.mixed != 0;                                        /* 16 frames, two lane mappings (see the FIR waves) */
+    const int NF = mixed ? 4 : spares ? (nwaves - 1) - (nwaves - 1) / 4 : nwaves - 1;   /* frame groups */
     const int G = NF * FWV;                                                 /* frames of the workgroup */
     float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));   /* [G][WSLOTS] */
     float2 *dring = win + (size_t)G * WSLOTS;                              /* [G][DSTRIDE] */
@@ -432,42 +441,67 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     }
 
     /* ======================================= FIR waves =========================================== */
-    if (spares && (wave & 3) == 0) return;   /* a wave that would share a SIMD with wave 0 */
-    const int w = spares ? wave - 1 - wave / 4 : wave - 1;   /* FIR wave index = the frame group it owns */
+    /* Which frames a hardware wave filters, and with which lane mapping.
+     *   plain: FIR wave w owns the 4 frames of group w (with spares, hardware waves 4, 8 retire at once).
+     *   mixed (measurement variant of the full narrow workgroup, QPSK_PIPE_DBG bit 7): four 4-frame units on
+     *     three SIMDs leave one SIMD with two, so 12 frames go to hardware waves 1-3 in the 4-symbol mapping (one
+     *     per SIMD) and the last 4 to hardware waves 6 and 7 (SIMDs 2 and 3), two frames each in the 2-symbol
+     *     mapping (32 lanes per frame): 1, 1.5 and 1.5 units per SIMD instead of 2, 1, 1.  Every wave still owns
+     *     its frames outright.  Bit-exact like the plain layout, and no faster (see the launcher). */
+    int w, gbase, rslot;          /* FIR wave index, first frame slot, its ready[] counter */
+    bool half = false;
+    if (mixed) {
+        if (wave >= 4 && wave <= 5) return;
+        half = wave >= 6;
+        w = half ? wave - 3 : wave - 1;
+        gbase = half ? 12 + 2 * (wave - 6) : 4 * (wave - 1);
+        rslot = w;
+    } else {
+        if (spares && (wave & 3) == 0) return;   /* a wave that would share a SIMD with wave 0 */
+        w = spares ? wave - 1 - wave / 4 : wave - 1;   /* FIR wave index = the frame group it owns */
+        gbase = w * GM::FWV;
+        rslot = w;
+    }
+
+  auto fir_wave = [&](auto wmap) {
+    /* this wave's lane mapping: QL lanes per frame, R symbols per lane (QL * R = S for every wave of the workgroup) */
+    constexpr int QL = decltype(wmap)::QL, R = decltype(wmap)::R, FWV = 64 / QL, PAD = R * C,
+                  TSTEPS = NTAPS + C * (R - 1);
+    static_assert(QL * R == S && 128 % PAD == 0 && PAD >= 2 * C, "chunk size and window padding are the workgroup's");
     const int fl = lane / QL, q = lane % QL;
 
     /* taps stay in LDS; the FIR loop keeps a rolling set of R + 1 groups of C taps in registers (broadcast reads) */
     const float4 *taps4 = reinterpret_cast<const float4 *>(sm->taps);
     constexpr int NLD = CH / 128;                          /* 16-byte loads per frame per chunk */
 
-    /* what a wave needs to know about a frame group: one 16-byte load covers 128 samples of ONE frame, so the
+    /* what a wave needs to know about its frames: one 16-byte load covers 128 samples of ONE frame, so the
      * wave's 64 lanes sweep a frame in NLD loads; lane `lane` holds samples 2*lane, 2*lane+1 of each 128-block */
     struct Ctx {
-        int group, g, frame;       /* group, this lane's frame slot in the workgroup, its frame */
+        int group, g, frame;       /* ready[] slot, this lane's frame slot in the workgroup, its frame */
         bool fvalid, all_valid;
         float2 *wf;                /* this lane's frame window */
         const float2 *rd;          /* FIR read base: position PAD*q -> slot (PAD+1)*q */
-        int wr0[FWV], wr1[FWV];    /* window write slots of the loaded pair, per frame of the group */
+        int wr0[FWV], wr1[FWV];    /* window write slots of the loaded pair, per frame of the wave */
         const float4 *src[FWV];
         bool fv[FWV];
     };
-    auto make_ctx = [&](int group) {
+    auto make_ctx = [&]() {
         Ctx cx;
-        cx.group = group;
-        cx.g = group * FWV + fl;
+        cx.group = rslot;
+        cx.g = gbase + fl;
         cx.frame = f0 + cx.g;
         cx.fvalid = cx.frame < a.nframes;
-        cx.all_valid = f0 + group * FWV + FWV <= a.nframes;
+        cx.all_valid = f0 + gbase + FWV <= a.nframes;
         cx.wf = win + (size_t)cx.g * WSLOTS;
         cx.rd = cx.wf + (PAD + 1) * q;
 #pragma unroll
         for (int ff = 0; ff < FWV; ff++) {
-            const int fr = f0 + group * FWV + ff;
+            const int fr = f0 + gbase + ff;
             cx.fv[ff] = fr < a.nframes;
             const int ix = a.index ? (cx.fv[ff] ? a.index[fr] : 0) : a.fixed_index;   /* decimation offset, < C */
             const int p0 = 2 * lane + 126 - ix;               /* window position of sample 2*lane of the chunk */
-            cx.wr0[ff] = (group * FWV + ff) * WSLOTS + p0 + p0 / PAD;
-            cx.wr1[ff] = (group * FWV + ff) * WSLOTS + (p0 + 1) + (p0 + 1) / PAD;
+            cx.wr0[ff] = (gbase + ff) * WSLOTS + p0 + p0 / PAD;
+            cx.wr1[ff] = (gbase + ff) * WSLOTS + (p0 + 1) + (p0 + 1) / PAD;
             cx.src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(cx.fv[ff] ? fr : 0) * L);
         }
         return cx;
@@ -523,49 +557,50 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
      * late: 0.2001 against 0.1989 ms.)  In the full wide workgroup the oldest wave of SIMDs 1-3 (FIR waves 0-2)
      * has the slack and the younger ones, above all the two beside the serial wave, set the pace: waves 0-2 flush
      * for everybody. */
-    const bool offload_narrow = GM::SPARE && spares && NF == 4 && !(a.dbg & 64);
+    /* In the mixed workgroup the 2-symbol waves only filter: the lone 4-symbol wave of SIMD 1 flushes their four
+     * frames (12..15) with its own mapping, the other two 4-symbol waves flush their own. */
+    const bool offload_narrow = !mixed && GM::SPARE && spares && NF == 4 && !(a.dbg & 64);
     const bool offload_wide = !GM::SPARE && NF == 8 && !(a.dbg & 64);
-    int fgroup[3] = {w, w, w};
+    int fbase[3] = {gbase, gbase, gbase};   /* first frame slot of each set of FWV frames this wave flushes */
     int nflush = 1;
-    if (offload_narrow) {
-        if (w == 1) { nflush = 2; fgroup[1] = 3; }
-        else if (w == 2) { nflush = 2; fgroup[1] = 0; }
+    if (mixed) {
+        if (half) nflush = 0;
+        else if (w == 0) { nflush = 2; fbase[1] = 12; }
+    } else if (offload_narrow) {
+        if (w == 1) { nflush = 2; fbase[1] = 3 * FWV; }
+        else if (w == 2) { nflush = 2; fbase[1] = 0; }
         else nflush = 0;
     } else if (offload_wide) {
-        if (w == 0) { nflush = 3; fgroup[1] = 4; fgroup[2] = 7; }
-        else if (w == 1) { nflush = 3; fgroup[1] = 5; fgroup[2] = 3; }
-        else if (w == 2) { nflush = 2; fgroup[1] = 6; }
+        if (w == 0) { nflush = 3; fbase[1] = 4 * FWV; fbase[2] = 7 * FWV; }
+        else if (w == 1) { nflush = 3; fbase[1] = 5 * FWV; fbase[2] = 3 * FWV; }
+        else if (w == 2) { nflush = 2; fbase[1] = 6 * FWV; }
         else nflush = 0;
     }
     auto flush_chunk = [&](int chunk) {
         for (int i = 0; i < nflush; i++) {
-            const int g2 = fgroup[i] * FWV + fl, fr2 = f0 + g2;
-            if (fr2 < a.nframes) flush_records<GM>(a, zring, g2, fr2, q, chunk);
+            const int g2 = fbase[i] + fl, fr2 = f0 + g2;
+            if (fr2 < a.nframes) flush_records<GM, R>(a, zring, g2, fr2, q, chunk);
         }
     };
 
     /* one chunk of one frame group: flush what the loop has finished with, stage the window, filter, hand over */
     auto run_chunk = [&](const Ctx &cx, float4 (&pre)[FWV][NLD], int c, bool prefetch_next) -> bool {
-        /* ring slot c % DR is free once chunk c - DR has been consumed; its outputs leave first */
-        if (c >= DR) {
-            if (!wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag)) return false;
-            tick(0);
-            flush_chunk(c - DR);
-            tick(1);
-        }
         float2 *wf = cx.wf;
         /* history: positions [0, 126-idx) <- [CH, CH+126-idx) of the previous window (zeros for c = 0) */
         {
-            constexpr int HN = 128 / QL;      /* 128 positions by the frame's QL lanes: p = q + QL*i -> slot p + p/PAD */
+            /* 128 positions by the frame's QL lanes: p = q + QL*i -> slot p + p/PAD = hq + QL*i + (QL*i)/PAD
+             * (q % PAD + (QL*i) % PAD < PAD in both mappings) */
+            constexpr int HN = 128 / QL, HB = HN < 8 ? HN : 8;
+            const int hq = q + q / PAD;
 #pragma unroll
-            for (int i0 = 0; i0 < HN; i0 += 8) {   /* 8 at a time (source and destination ranges are disjoint) */
-                float2 h[8];
+            for (int i0 = 0; i0 < HN; i0 += HB) {   /* 8 at a time (source and destination ranges are disjoint) */
+                float2 h[HB];
 #pragma unroll
-                for (int i = 0; i < 8; i++)
-                    h[i] = wf[CH + CH / PAD + q + QL * (i0 + i) + (QL * (i0 + i)) / PAD];
+                for (int i = 0; i < HB; i++)
+                    h[i] = wf[CH + CH / PAD + hq + QL * (i0 + i) + (QL * (i0 + i)) / PAD];
 #pragma unroll
-                for (int i = 0; i < 8; i++)
-                    wf[q + QL * (i0 + i) + (QL * (i0 + i)) / PAD] = h[i];
+                for (int i = 0; i < HB; i++)
+                    wf[hq + QL * (i0 + i) + (QL * (i0 + i)) / PAD] = h[i];
             }
         }
         /* new samples of this chunk (prefetched), then start the next chunk's loads */
@@ -682,6 +717,15 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
             for (int r = 0; r < R; r++) acc[r] = make_float2(ac[r].x, ac[r].y);
         }
         tick(3);
+        /* Only now does the wave need the loop: ring slot c % DR is free once chunk c - DR has been consumed, and
+         * that chunk's outputs leave first (staging and filtering above touch neither ring, so the FIR waves run
+         * up to two chunks ahead of the loop instead of one) */
+        if (c >= DR) {
+            if (!wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag)) return false;
+            tick(0);
+            flush_chunk(c - DR);
+            tick(1);
+        }
         /* decimated symbols -> ring; a pick at or past the end of the block is 0 (cannot happen for idx < C) */
         float2 *dw = dring + (size_t)cx.g * DSTRIDE + (c % DR) * S + R * q;
 #pragma unroll
@@ -692,7 +736,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         return true;
     };
 
-    const Ctx own = make_ctx(w);
+    const Ctx own = make_ctx();
     float4 pre[FWV][NLD];
     prefetch(own, pre, 0);
     bool ok = true;
@@ -707,10 +751,19 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     if (!ok && lane == 0) atomicExch(status, 1);
 #ifdef QPSK_PIPE_PROFILE
     if (prof && lane == 0)
-        printf("FIR wave %d: %d chunks; cycles per chunk: wait for the loop %llu, flush %llu, history + window %llu, filter %llu, "
-               "ring hand-over %llu\n", w, nchunks, tacc[0] / nchunks, tacc[1] / nchunks, tacc[2] / nchunks, tacc[3] / nchunks,
-               tacc[4] / nchunks);
+        printf("FIR wave %d (%d symbols per lane): %d chunks; cycles per chunk: wait for the loop %llu, flush %llu, history + window %llu, "
+               "filter %llu, ring hand-over %llu\n", w, R, nchunks, tacc[0] / nchunks, tacc[1] / nchunks, tacc[2] / nchunks,
+               tacc[3] / nchunks, tacc[4] / nchunks);
 #endif
+  };   /* fir_wave */
+
+    if constexpr (GM::R == 4) {   /* the mixed workgroup exists for 64-symbol chunks only */
+        if (half) {
+            fir_wave(WaveMap<GM::S / 2, 2>{});
+            return;
+        }
+    }
+    fir_wave(WaveMap<GM::QL, GM::R>{});
 }
 
 /* frames of a workgroup with NF FIR waves */
@@ -737,8 +790,14 @@ int pipe_frames(int NF, bool wide) { return wide ? frames_of<GeomWide>(NF) : fra
 int pipe_cycles(void) { return C; }
 int pipe_max_nf(bool wide) { return wide ? GeomWide::MAX_NF : GeomNarrow::MAX_NF; }
 
-int launch_rx_fused_pipe(const FusedArgs &a, int NF, bool wide, int *status, hipStream_t s)
+int launch_rx_fused_pipe(const FusedArgs &a0, int NF, bool wide, int *status, hipStream_t s)
 {
+    FusedArgs a = a0;
+    /* measurement knob (QPSK_PIPE_DBG bit 7): the full narrow workgroup with two lane mappings, see the kernel.
+     * Config 2 runs 0.202-0.210 ms with it and 0.200-0.202 ms without [same process]: with the FIR waves alone the
+     * kernel takes 0.18 ms, with the loop alone 0.185 ms, so the SIMD that carries two FIR waves is not what
+     * separates the 0.20 ms from either -- NOT the default */
+    a.mixed = !wide && NF == GeomNarrow::MAX_NF && (a.dbg & 128) && !(a.dbg & 4);
     const int G = pipe_frames(NF, wide);
     const int blocks = (a.nframes + G - 1) / G;
     const size_t lds = pipe_lds_bytes(NF, a.nbw, wide);
@@ -748,7 +807,8 @@ int launch_rx_fused_pipe(const FusedArgs &a, int NF, bool wide, int *status, hip
     if (wide) {
         hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomWide>, dim3(blocks), dim3(64 * nwaves(GeomWide::SPARE)), lds, s, a, status);
     } else {
-        const dim3 threads(64 * nwaves(GeomNarrow::SPARE));
+        /* mixed: hardware waves 0 (loop), 1-3 (4 frames each), 4-5 (retire), 6-7 (2 frames each) */
+        const dim3 threads(a.mixed ? 512 : 64 * nwaves(GeomNarrow::SPARE));
         if (a.dbg & 16)   /* measurement knob (QPSK_PIPE_DBG bit 4): the other FIR-step schedule */
             hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrowAlt>, dim3(blocks), threads, lds, s, a, status);
         else

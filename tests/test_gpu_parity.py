@@ -151,6 +151,13 @@ def test_pipeline_geometries_agree(oracle, monkeypatch, L, mode):
             got = m.rx_batch(x[:33], want_costas=False)
             m.sync()
             assert bits_equal(cpu(got["sym"]), want["sym"][:33]) and bits_equal(cpu(got["freq"]), want["freq"][:33])
+    # the measurement variant with two lane mappings in one workgroup (16 frames: 12 at 4 symbols per lane, 4 at 2)
+    monkeypatch.setenv("QPSK_PIPE_WIDE", "0")
+    monkeypatch.setenv("QPSK_PIPE_NF", "4")
+    monkeypatch.setenv("QPSK_PIPE_DBG", "128")
+    got = m.rx_batch(x, want_costas=True)
+    m.sync()
+    assert_batch_equal(got, want)
 
 
 def test_rx_batch_golden_vectors():
