@@ -1,0 +1,63 @@
+"""bench.py prints ONE JSON line with the fields the driver and the judge read; smoke() runs the hot path against the
+oracle.  Small shapes: the numbers themselves are bench.py's business, the contract is what is checked here."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout          # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_defaults_are_the_contract_defaults():
+    """no flags = 1 GPU and a K/W that let the clocks settle (a step is 0.2 ms)"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"--gpus", type=int, default=1' in src
+    assert '"--steps", type=int, default=200' in src and '"--warmup", type=int, default=20' in src
+
+
+@pytest.mark.gpu
+def test_bench_json_line():
+    d = run_bench("--steps", "5", "--warmup", "2", "--frames", "256", "--cpu-frames", "8")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "Msamples/s" and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    # value is the whole job over the wall clock of the K steps
+    want = d["config"]["frames_per_gpu"] * d["config"]["frame_size"] / (d["ms_per_step"] * 1e-3) / 1e6
+    assert abs(d["value"] - want) / want < 1e-6
+    rl = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rl, k
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and rl["peak"] == 8000.0
+    assert abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-12
+    # achieved = algorithmic bytes per launch over the kernel's average duration
+    assert abs(rl["achieved"] - rl["algorithmic_bytes_per_launch"] / (rl["kernel_ms"] * 1e-3) / 1e9) / rl["achieved"] < 1e-9
+    assert rl["algorithmic_bytes_per_launch"] == 8 * 256 * d["config"]["frame_size"]
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    p = d["parity"]
+    assert p["symbol_mismatches"] == 0 and p["freq_bit_mismatches"] == 0 and p["phase_bit_mismatches"] == 0
+
+
+@pytest.mark.gpu
+def test_smoke_entry_point():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.smoke()
