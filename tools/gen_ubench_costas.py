@@ -3,6 +3,10 @@
 (qpsk_amd/csrc/costas_asm.h) to learn what each part costs on gfx950.  Measurement tooling, not product code;
 the variants that drop parts compute wrong values on purpose (timing only).
 
+Historical: this models the FIRST hand-scheduled stream (compare/select detector, 8-byte records).  The stream has
+since been measured in place instead -- timing-only edits of costas_asm.h built as a second library and alternated
+with the product build in one process by tools/ab_libs.py.
+
     python tools/gen_ubench_costas.py && hipcc --offload-arch=gfx950 -O3 -ffp-contract=off \
         build_tools/ubench_costas_var.hip -o build_tools/ubench_costas_var
 """
