@@ -211,39 +211,66 @@ rrc_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ memory, 
      * position 8*tid + r + k, so step t = r + k reads position 8*tid + t once for all r */
     const float2 *rd = xs + 9 * tid;
     const float4 *taps4 = reinterpret_cast<const float4 *>(taps);
-    float2 acc[FR];
-#pragma unroll
-    for (int r = 0; r < FR; r++)
-        acc[r] = make_float2(0.0f, 0.0f);
-    float tg[2][8];
-#pragma unroll
-    for (int tb = 0; tb * 8 < NTAPS + FR - 1; tb++) {
+    /* Left to itself the compiler emits each multiply-add as v_pk_mul, s_nop, dependent v_pk_add (357 s_nops and
+     * as many stalls in 2032 packed operations).  As in rx_fused.hip the order inside a window position is pinned
+     * with empty asm statements: the up to 8 products of the position, then the 8 adds, so that a product is 8
+     * instructions ahead of its add and an accumulator's adds are 16 apart.  Window values and tap groups are
+     * fetched one block of 8 positions ahead (three tap groups live: a position's 8 outputs reach back into the
+     * previous group).  The sum per output is still taps 0..126 in order in one accumulator. */
+    constexpr int TS = NTAPS + FR - 1, NB = (TS + 7) / 8;
+    static_assert(FR == 8, "the pinned step names 8 products");
+    float tg[3][8];
+    float2 wv[2][8];
+    auto fetch_block = [&](int tb) {
         if (tb * 8 < NTAPS) {
             const float4 ta = taps4[2 * tb], tc = taps4[2 * tb + 1];
-            tg[tb & 1][0] = ta.x; tg[tb & 1][1] = ta.y; tg[tb & 1][2] = ta.z; tg[tb & 1][3] = ta.w;
-            tg[tb & 1][4] = tc.x; tg[tb & 1][5] = tc.y; tg[tb & 1][6] = tc.z; tg[tb & 1][7] = tc.w;
+            float *g_ = tg[tb % 3];
+            g_[0] = ta.x; g_[1] = ta.y; g_[2] = ta.z; g_[3] = ta.w;
+            g_[4] = tc.x; g_[5] = tc.y; g_[6] = tc.z; g_[7] = tc.w;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int t = tb * 8 + u;
-            if (t < NTAPS + FR - 1) {
-                const float2 v = rd[t + (t >> 3)];
-#pragma unroll
-                for (int r = 0; r < FR; r++) {
-                    const int k = t - r;
-                    if (k >= 0 && k < NTAPS) fir_mac(acc[r], v, tg[(k >> 3) & 1][k & 7]);
-                }
-            }
+            if (t < TS) wv[tb & 1][u] = rd[t + (t >> 3)];
         }
-        /* keep the scheduler from hoisting every later window read above this block (it would need ~470
-         * registers and leave one workgroup per CU with nothing to overlap its load/store phases with) */
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    v2f ac[FR];
+#pragma unroll
+    for (int r = 0; r < FR; r++) ac[r] = v2f{0.0f, 0.0f};
+    fetch_block(0);
+    static_for<0, NB>([&](auto tbc) {
+        constexpr int tb = decltype(tbc)::value;
+        if (tb + 1 < NB) fetch_block(tb + 1);
+        static_for<0, 8>([&](auto uc) {
+            constexpr int u = decltype(uc)::value, t = tb * 8 + u;
+            if constexpr (t < TS) {
+                const v2f v = v2f{wv[tb & 1][u].x, wv[tb & 1][u].y};
+                v2f p[FR];   /* re*tap, im*tap (rrc_fir.c:24-25); output r takes tap k = t - r */
+                static_for<0, FR>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value, k = t - r;
+                    if constexpr (k >= 0 && k < NTAPS) p[r] = v * tg[(k >> 3) % 3][k & 7];
+                });
+                if constexpr (t >= FR - 1 && t < NTAPS) {
+                    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+                } else {   /* the first 7 and the last 7 positions: fewer outputs are in range */
+#define QPSK_PIN_P(r) if constexpr (t - (r) >= 0 && t - (r) < NTAPS) asm volatile("" : "+v"(p[r]))
+                    QPSK_PIN_P(0); QPSK_PIN_P(1); QPSK_PIN_P(2); QPSK_PIN_P(3);
+                    QPSK_PIN_P(4); QPSK_PIN_P(5); QPSK_PIN_P(6); QPSK_PIN_P(7);
+#undef QPSK_PIN_P
+                }
+                static_for<0, FR>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value, k = t - r;
+                    if constexpr (k >= 0 && k < NTAPS) ac[r] = ac[r] + p[r];
+                });
+                asm volatile("" : "+v"(ac[0]), "+v"(ac[1]), "+v"(ac[2]), "+v"(ac[3]), "+v"(ac[4]), "+v"(ac[5]), "+v"(ac[6]), "+v"(ac[7]));
+            }
+        });
+    });
     __syncthreads();
     /* transpose through LDS: lane-major results -> sample-major coalesced stores */
 #pragma unroll
     for (int r = 0; r < FR; r++)
-        xs[9 * tid + r] = fir_gain(acc[r]);
+        xs[9 * tid + r] = fir_gain(make_float2(ac[r].x, ac[r].y));
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < FR; j++) {

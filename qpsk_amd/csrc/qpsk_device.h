@@ -25,6 +25,23 @@ constexpr double TAU = 2.0 * 3.14159265358979323846; /* qpsk.h:29 */
 constexpr float TAU_F = 0x1.921fb6p+2f; /* the float just above TAU: "phase > TAU" <=> phase >= TAU_F */
 constexpr float ROT45 = 0x1.6a09e6p-1f; /* cosf((float)(M_PI/4)) == sinf(same), qpsk.h:30, qpsk.c:75 */
 
+/* tools of the hand-ordered FIR loops (rx_fused.hip, rrc_fir_kernel) */
+typedef float v2f __attribute__((ext_vector_type(2)));   /* one VGPR pair: operand type of the packed fp32 ops */
+
+template <int I>
+struct IntC { static constexpr int value = I; };
+
+/* f(IntC<I>{}) for I = FIRST .. LAST-1, expanded at compile time (the compiler does not unroll a loop with an
+ * asm statement in it) */
+template <int FIRST, int LAST, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (FIRST < LAST) {
+        f(IntC<FIRST>{});
+        static_for<FIRST + 1, LAST>(f);
+    }
+}
+
 /* rrc_fir.c:28: "sample[j] = y * GAIN": complex float times double, narrowed */
 __device__ __forceinline__ float2 fir_gain(float2 y)
 {

@@ -47,21 +47,6 @@ namespace qpsk {
 
 namespace pipe {
 
-typedef float v2f __attribute__((ext_vector_type(2)));   /* one VGPR pair: operand type of the packed fp32 ops */
-
-template <int I>
-struct IntC { static constexpr int value = I; };
-
-/* f(IntC<I>{}) for I = FIRST .. LAST-1, expanded at compile time */
-template <int FIRST, int LAST, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (FIRST < LAST) {
-        f(IntC<FIRST>{});
-        static_for<FIRST + 1, LAST>(f);
-    }
-}
-
 constexpr int C = 8;            /* CYCLES this instantiation is built for */
 constexpr int DR = 2;            /* depth of the symbol rings in chunks */
 constexpr int MAX_WAVES = 8;     /* FIR waves of the widest geometry */
