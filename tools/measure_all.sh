@@ -4,7 +4,7 @@ O=gpurun_out
 set -e
 python3 bench.py > $O/bench.json 2> $O/bench.err
 prof() { d=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$d -- "$@" > $O/$d.log 2>&1; }
-prof prof_bench python3 bench.py --steps 20 --warmup 3 --cpu-frames 0
+prof prof_bench python3 bench.py --cpu-frames 0        # bench.py's default steps and warmup: the same command, CPU leg off
 prof prof_8192 python3 tools/sweep.py --frames 8192
 prof prof_fft python3 tools/sweep.py --timing fft
 prof prof_hist2 python3 tools/sweep.py --timing hist
