@@ -184,6 +184,21 @@ def test_extreme_inputs(oracle):
         assert_batch_equal(got, want)
 
 
+@pytest.mark.parametrize("offset_hz,bw", [(200.0, BW), (-250.0, np.float32(0.3)), (270.0, np.float32(0.6))])
+def test_carrier_offsets_wrap_often(oracle, offset_hz, bw):
+    """loops that settle at 0.5 .. 1 rad/symbol, of either sign and up to the clamp (costas_loop.c:69-74): the phase
+    runs through 2 pi every 6 to 12 symbols, so the out-of-line wrap (costas_loop.c:61-67) of every step position of
+    the hand-scheduled stream is taken many times per frame"""
+    fs, rs, L, F = 19200.0, 2400.0, 8192, 24
+    m = modem(fs=fs, rs=rs, frame_size=L, loop_bw=bw, timing_mode=TIMING_FIXED, fixed_index=6)
+    x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=offset_hz, base_seed=int(abs(offset_hz)), noise=0.1)
+    want = oracle.rx_batch(x, fs, rs, loop_bw=bw, timing_mode=TIMING_FIXED, fixed_index=6, want_costas=True)
+    got = m.rx_batch(x, want_costas=True)
+    m.sync()
+    assert_batch_equal(got, want)
+    assert np.abs(want["freq"]).max() > 0.5
+
+
 def test_loop_bandwidth_sweep(oracle):
     """README.md:12: loop bandwidth TAU/100 .. TAU/200, several loops sharing one FIR pass (config 5)"""
     fs, rs, L, F = 9600.0, 1200.0, 8192, 7
