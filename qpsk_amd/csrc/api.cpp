@@ -429,14 +429,15 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
                          ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames(1, false) <= 64 &&
                          !env_int("QPSK_FUSED_GENERIC", 0);
     if (pipe_ok) {
-        /* geometry: a batch that leaves at most 16 frames to a CU is bounded by the recurrence and takes the
-         * narrow workgroups (16 frames, serial wave alone on its SIMD); a bigger one is bounded by the FIR
-         * waves and takes the wide ones (32 frames, two FIR waves per SIMD) -- see rx_fused.hip */
+        /* geometry: the narrow workgroups (16 frames, the serial wave alone on its SIMD) for every batch size; a
+         * batch above 16 frames per CU runs them in rounds.  The wide ones (32 frames, FIR waves beside the serial
+         * wave) were the faster choice for such batches while the serial wave wrote 16-byte records every step
+         * (8192 frames: 0.345 against 0.373 ms); with the phase records it is the other way round (0.379 against
+         * 0.348 ms), so they are kept for QPSK_PIPE_WIDE=1 only -- see rx_fused.hip */
         auto fits = [&](int nf_, bool wide_) {   /* one lane of the serial wave per (frame, loop); rings grow with the loops */
             return pipe_frames(nf_, wide_) * nbw <= 64 && pipe_lds_bytes(nf_, nbw, wide_) <= (size_t)MAX_LDS_BYTES;
         };
-        bool wide = nframes > c->ncu * pipe_frames(pipe_max_nf(false), false) && fits(pipe_max_nf(true), true);
-        wide = env_int("QPSK_PIPE_WIDE", wide ? 1 : 0) != 0;
+        const bool wide = env_int("QPSK_PIPE_WIDE", 0) != 0 && fits(1, true);
         const int full = pipe_max_nf(wide);
         int nf = full;
         if (!wide) {   /* just enough FIR waves to give every CU one workgroup */

@@ -76,21 +76,20 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     "v_mul_f64 v[108:109], v[106:107], v[106:107]\n\t"
 
 /*
- * the same head with the previous step's leftovers in its empty issue slots: that step's record (offset ZPREV),
- * its clamped frequency (-> FIN, this step's input), its exact-zero test, and the 2*pi test of its phase PIN.
- * The head runs on the unwrapped PIN; LW (QPSK_WRAP_HEAD) wraps PIN in place, redoes the head, returns to LR.
+ * the same head with an independent instruction in four of its five empty issue slots: the 2*pi test of its phase
+ * PIN and the previous step's leftovers -- its clamped frequency (-> FIN, this step's input) and its exact-zero
+ * test.  The head runs on the unwrapped PIN; LW (QPSK_WRAP_HEAD) wraps PIN in place, redoes the head, returns to LR.
  */
-#define QPSK_HEAD_DEFERRED(PIN, FIN, ZPREV, LW, LR)                                                           \
+#define QPSK_HEAD_DEFERRED(PIN, FIN, LW, LR)                                                                  \
     "v_cvt_f64_f32 v[100:101], " PIN "\n\t"                                                                   \
-    "ds_write_b96 %[za], v[114:116] offset:" QPSK_STR(ZPREV) "\n\t"                                           \
     "v_cmp_ge_f32_e64 vcc, |" PIN "|, %[tau]\n\t"                                                             \
     "v_fma_f64 v[116:117], v[100:101], %[k2pi], %[magic]\n\t"                                                 \
     "v_med3_f32 " FIN ", v118, %[fmin], %[fmax]\n\t"                                                          \
     "v_add_f64 v[104:105], v[116:117], -%[magic]\n\t"                                                         \
     "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
     "v_fma_f64 v[106:107], -v[104:105], %[hpi], v[100:101]\n\t"                                               \
-    "s_cbranch_vccnz " LW "f\n\t"                                                                             \
-    "v_mul_f64 v[108:109], v[106:107], v[106:107]\n"                                                          \
+    "v_mul_f64 v[108:109], v[106:107], v[106:107]\n\t"                                                        \
+    "s_cbranch_vccnz " LW "f\n"                                                                               \
     LR ":\n\t"
 
 /*
@@ -99,7 +98,7 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
  * unwrapped, in POUT.  DREG = the VGPR pair holding this step's symbol, WAIT = the lgkmcnt wait in front of
  * its first use, READ = the LDS fetch of the pair after next (even steps) or nothing.
  */
-#define QPSK_BODY(PIN, FIN, POUT, DREG, WAIT, READ)                                                           \
+#define QPSK_BODY(PIN, FIN, POUT, DREG, WAIT, READ, QW)                                                       \
     "v_fma_f64 v[110:111], v[108:109], %[c4], %[c3]\n\t"                                                      \
     "v_fma_f64 v[112:113], v[108:109], %[s3], %[s2]\n\t"                                                      \
     "v_fma_f64 v[110:111], v[108:109], v[110:111], %[c2]\n\t"                                                 \
@@ -115,6 +114,7 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     "v_pk_mul_f32 v[104:105], " DREG ", v[112:113] op_sel:[1,0] op_sel_hi:[0,0]\n\t"                          \
     READ                                                                                                      \
     "v_pk_add_f32 v[114:115], v[100:101], v[104:105] neg_hi:[0,1]\n\t"                                        \
+    QW                                                                                                        \
     "v_sub_f32_e64 v106, |v115|, |v114|\n\t"                  /* d = |T.y| - |T.x|;  e = s d */                  \
     "v_xor_b32_e32 v108, v114, v115\n\t"                      /* sign bit of s = sgn(T.x) sgn(T.y) */            \
     "v_pk_mul_f32 v[102:103], %[beal], v[106:107] op_sel_hi:[1,0]\n\t"   /* (beta d, alpha d) */                \
@@ -123,10 +123,9 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     "v_add_f32_e32 v119, " PIN ", v118\n\t"                                                                   \
     "v_fma_f32 " POUT ", v108, v103, v119\n\t"                /* (phase + freq) + alpha e */
 
-/* the leftovers of a group's LAST step, in line: record at ZOFF, clamp -> FOUT, zero test, 2*pi test of POUT */
-#define QPSK_TAIL(POUT, FOUT, ZOFF, LW, LR)                                                                   \
+/* the leftovers of a group's LAST step, in line: clamp -> FOUT, zero test, 2*pi test of POUT */
+#define QPSK_TAIL(POUT, FOUT, LW, LR)                                                                         \
     "v_cmp_ge_f32_e64 vcc, |" POUT "|, %[tau]\n\t"                                                            \
-    "ds_write_b96 %[za], v[114:116] offset:" QPSK_STR(ZOFF) "\n\t"                                            \
     "v_med3_f32 " FOUT ", v118, %[fmin], %[fmax]\n\t"                                                         \
     "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
     "s_cbranch_vccnz " LW "f\n"                                                                               \
@@ -141,7 +140,8 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     "v_cmp_ge_f32_e64 vcc, |" P "|, %[tau]\n\t"                                                               \
     "s_or_b64 %[fl], %[fl], vcc\n\t"
 
-/* out-of-line wrap for QPSK_HEAD_DEFERRED: v[100:101] still holds (double)PIN; wrap, then the head again */
+/* out-of-line wrap for QPSK_HEAD_DEFERRED: v[100:101] still holds (double)PIN; wrap PIN where it stands (the
+ * record written later is the WRAPPED phase, the one the step uses), then the head again */
 #define QPSK_WRAP_HEAD(PIN, LW, LR)                                                                           \
     LW ":\n\t"                                                                                                \
     QPSK_WRAP_ONCE(PIN)                                                                                       \
@@ -156,24 +156,33 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     "s_branch " LR "b\n"
 
 /* symbol pairs alternate between two register sets, each fetched TWO steps before its first use (the FIR waves
- * keep the LDS queue busy; one step of slack was not always enough): when a set is first used, the two record
- * writes issued since its read may still be in flight */
-#define QPSK_WAIT2 "s_waitcnt lgkmcnt(2)\n\t"
+ * keep the LDS queue busy; one step of slack was not always enough).  LDS operations complete in order, so the
+ * wait in front of a set's first use allows as many outstanding ones as were issued after its read: the record
+ * write of the step before (steps 0, 4, 8, 12) or none (steps 2, 6, 10, 14) */
+#define QPSK_WAIT0 "s_waitcnt lgkmcnt(0)\n\t"
+#define QPSK_WAIT1 "s_waitcnt lgkmcnt(1)\n\t"
 #define QPSK_RDA(OFF) "ds_read_b128 v[120:123], %[da] offset:" QPSK_STR(OFF) "\n\t"
 #define QPSK_RDB(OFF) "ds_read_b128 v[136:139], %[da] offset:" QPSK_STR(OFF) "\n\t"
+/* the records of four steps, their starting phases v140..v143, in one write (issued by the fourth of them once its
+ * own phase has been through the 2*pi test, before its update overwrites v140) */
+#define QPSK_QW(OFF) "ds_write_b128 %[za], v[140:143] offset:" QPSK_STR(OFF) "\n\t"
 
-/* steps 1..14 of a group come in pairs (odd, even): phase/freq v132,v133 -> v134,v135 -> v132,v133; Z_O/Z_E =
- * record offsets of the steps BEFORE the odd and the even one, LO_O/LO_E their symbol registers, RD the fetch the
- * even step issues */
-#define QPSK_STEP_PAIR(Z_O, Z_E, LO_O, LO_E, RD, LW1, LR1, LW2, LR2)                                          \
-    QPSK_HEAD_DEFERRED("v132", "v133", Z_O, LW1, LR1)                                                         \
-    QPSK_BODY("v132", "v133", "v134", LO_O, "", "")                                                           \
-    QPSK_HEAD_DEFERRED("v134", "v135", Z_E, LW2, LR2)                                                         \
-    QPSK_BODY("v134", "v135", "v132", LO_E, QPSK_WAIT2, RD)
+/* four steps k = 4m .. 4m+3 (k > 0): the phase of step k lives in v140 + k % 4, the clamped frequency in v133
+ * (odd k) or v135 (even k); SA/SB = the symbol sets of the first and the second pair, RD1/RD2 the fetches of the
+ * two even steps, QOFF the byte offset of the four records, P4 where the fourth step leaves the next phase */
+#define QPSK_STEP_QUAD(SA_LO, SA_HI, SB_LO, SB_HI, RD1, RD2, QOFF, P4, L1, L2, L3, L4)                          \
+    QPSK_HEAD_DEFERRED("v140", "v135", "1" L1, "2" L1)                                                        \
+    QPSK_BODY("v140", "v135", "v141", SA_LO, QPSK_WAIT1, RD1, "")                                             \
+    QPSK_HEAD_DEFERRED("v141", "v133", "1" L2, "2" L2)                                                        \
+    QPSK_BODY("v141", "v133", "v142", SA_HI, "", "", "")                                                      \
+    QPSK_HEAD_DEFERRED("v142", "v135", "1" L3, "2" L3)                                                        \
+    QPSK_BODY("v142", "v135", "v143", SB_LO, QPSK_WAIT0, RD2, "")                                             \
+    QPSK_HEAD_DEFERRED("v143", "v133", "1" L4, "2" L4)                                                        \
+    QPSK_BODY("v143", "v133", P4, SB_HI, "", "", QPSK_QW(QOFF))
 
 /*
  * Runs up to `groups` groups of COSTAS_ASM_GROUP steps starting at LDS addresses d_addr (symbols, 8 bytes each,
- * 16-byte aligned) and z_addr (records, 16 bytes each); both are advanced on return.  Returns the number of
+ * 16-byte aligned) and z_addr (records, 4 bytes each, 16-byte aligned); both are advanced on return.  Returns the number of
  * groups NOT done: 0, or -- if the flag word is nonzero -- the abandoned group and everything after it, with
  * phase/freq restored to that group's start.  freq must not be -0.0f (see the header).
  */
@@ -198,27 +207,27 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         "v_mov_b32 v130, %[p]\n\t"
         "v_mov_b32 v131, %[f]\n\t"
         "v_mov_b32 v126, 0x7f800000\n\t"        /* running min of |T.x|, |T.y| over the group: 0 <=> some exact zero */
-        /* step 0 */
-        QPSK_HEAD_CHAIN("%[p]")
-        QPSK_BODY("%[p]", "%[f]", "v132", "v[120:121]", QPSK_WAIT2, QPSK_RDB(16))
-        /* steps 1..14 */
-        QPSK_STEP_PAIR(0, 16, "v[122:123]", "v[136:137]", QPSK_RDA(32), "101", "201", "102", "202")
-        QPSK_STEP_PAIR(32, 48, "v[138:139]", "v[120:121]", QPSK_RDB(48), "103", "203", "104", "204")
-        QPSK_STEP_PAIR(64, 80, "v[122:123]", "v[136:137]", QPSK_RDA(64), "105", "205", "106", "206")
-        QPSK_STEP_PAIR(96, 112, "v[138:139]", "v[120:121]", QPSK_RDB(80), "107", "207", "108", "208")
-        QPSK_STEP_PAIR(128, 144, "v[122:123]", "v[136:137]", QPSK_RDA(96), "109", "209", "110", "210")
-        QPSK_STEP_PAIR(160, 176, "v[138:139]", "v[120:121]", QPSK_RDB(112), "111", "211", "112", "212")
-        QPSK_STEP_PAIR(192, 208, "v[122:123]", "v[136:137]", QPSK_RDA(128), "113", "213", "114", "214")
-        /* step 15 and its own leftovers */
-        QPSK_HEAD_DEFERRED("v132", "v133", 224, "115", "215")
-        QPSK_BODY("v132", "v133", "%[p]", "v[138:139]", "", "")
-        QPSK_TAIL("%[p]", "%[f]", 240, "116", "216")
+        "v_mov_b32 v140, %[p]\n\t"
+        /* steps 0..3: the first has no predecessor in the group */
+        QPSK_HEAD_CHAIN("v140")
+        QPSK_BODY("v140", "%[f]", "v141", "v[120:121]", QPSK_WAIT1, QPSK_RDB(16), "")
+        QPSK_HEAD_DEFERRED("v141", "v133", "101", "201")
+        QPSK_BODY("v141", "v133", "v142", "v[122:123]", "", "", "")
+        QPSK_HEAD_DEFERRED("v142", "v135", "102", "202")
+        QPSK_BODY("v142", "v135", "v143", "v[136:137]", QPSK_WAIT0, QPSK_RDA(32), "")
+        QPSK_HEAD_DEFERRED("v143", "v133", "103", "203")
+        QPSK_BODY("v143", "v133", "v140", "v[138:139]", "", "", QPSK_QW(0))
+        /* steps 4..15 */
+        QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(48), QPSK_RDA(64), 16, "v140", "04", "05", "06", "07")
+        QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(80), QPSK_RDA(96), 32, "v140", "08", "09", "10", "11")
+        QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(112), QPSK_RDA(128), 48, "%[p]", "12", "13", "14", "15")
+        QPSK_TAIL("%[p]", "%[f]", "116", "216")
         "v_cmp_eq_f32_e64 %[tm], 0, v126\n\t"
         "s_or_b64 %[fl], %[fl], %[tm]\n\t"
         "s_cmp_lg_u64 %[fl], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
         "v_add_u32_e32 %[da], 0x80, %[da]\n\t"
-        "v_add_u32_e32 %[za], 0x100, %[za]\n\t"
+        "v_add_u32_e32 %[za], 0x40, %[za]\n\t"
         "s_sub_u32 %[ng], %[ng], 1\n\t"
         "s_cmp_lg_u32 %[ng], 0\n\t"
         "s_cbranch_scc1 2b\n\t"
@@ -227,21 +236,21 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         "v_mov_b32 %[p], v130\n\t"
         "v_mov_b32 %[f], v131\n\t"
         "s_branch 4f\n"
-        QPSK_WRAP_HEAD("v132", "101", "201")
-        QPSK_WRAP_HEAD("v134", "102", "202")
-        QPSK_WRAP_HEAD("v132", "103", "203")
-        QPSK_WRAP_HEAD("v134", "104", "204")
-        QPSK_WRAP_HEAD("v132", "105", "205")
-        QPSK_WRAP_HEAD("v134", "106", "206")
-        QPSK_WRAP_HEAD("v132", "107", "207")
-        QPSK_WRAP_HEAD("v134", "108", "208")
-        QPSK_WRAP_HEAD("v132", "109", "209")
-        QPSK_WRAP_HEAD("v134", "110", "210")
-        QPSK_WRAP_HEAD("v132", "111", "211")
-        QPSK_WRAP_HEAD("v134", "112", "212")
-        QPSK_WRAP_HEAD("v132", "113", "213")
-        QPSK_WRAP_HEAD("v134", "114", "214")
-        QPSK_WRAP_HEAD("v132", "115", "215")
+        QPSK_WRAP_HEAD("v141", "101", "201")
+        QPSK_WRAP_HEAD("v142", "102", "202")
+        QPSK_WRAP_HEAD("v143", "103", "203")
+        QPSK_WRAP_HEAD("v140", "104", "204")
+        QPSK_WRAP_HEAD("v141", "105", "205")
+        QPSK_WRAP_HEAD("v142", "106", "206")
+        QPSK_WRAP_HEAD("v143", "107", "207")
+        QPSK_WRAP_HEAD("v140", "108", "208")
+        QPSK_WRAP_HEAD("v141", "109", "209")
+        QPSK_WRAP_HEAD("v142", "110", "210")
+        QPSK_WRAP_HEAD("v143", "111", "211")
+        QPSK_WRAP_HEAD("v140", "112", "212")
+        QPSK_WRAP_HEAD("v141", "113", "213")
+        QPSK_WRAP_HEAD("v142", "114", "214")
+        QPSK_WRAP_HEAD("v143", "115", "215")
         QPSK_WRAP_TAIL("%[p]", "116", "216")
         "4:\n\t"
         "s_waitcnt lgkmcnt(0)"
@@ -254,7 +263,7 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
           "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
           "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135",
-          "v136", "v137", "v138", "v139");
+          "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143");
     flags_out = flags;
     return groups;
 }

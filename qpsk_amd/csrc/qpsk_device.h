@@ -169,6 +169,23 @@ __device__ __forceinline__ float detector(float zx, float zy)
     return (zx > 0.0f ? zy : -zy) - (zy > 0.0f ? zx : -zx);
 }
 
+/*
+ * costas_frame[] of one symbol (qpsk.c:197) from the phase the loop held BEFORE that symbol's step -- what the
+ * consumer of a phase record computes, operation for operation what the step itself formed (T, then the quadrant).
+ * FIRST = the frame's first symbol: its phase may be a loaded -0, so it takes the form that is exact there too,
+ * like the step that consumed it.
+ */
+template <bool FIRST>
+__device__ __forceinline__ float2 derotate(float phase, float2 d)
+{
+    if (FIRST) {
+        const SinCos w = sincos_f32(phase);
+        return make_float2(d.x * w.c + d.y * w.s, d.y * w.c - d.x * w.s);
+    }
+    const SinCosRaw w = sincos_raw_horner(phase);
+    return apply_quadrant(d.x * w.c + d.y * w.s, d.y * w.c - d.x * w.s, w.n);
+}
+
 template <bool FAST_CLAMP>
 __device__ __forceinline__ void costas_step_t(float &phase, float &freq, float alpha, float beta, float min_freq,
                                               float max_freq, float2 d, float &tx, float &ty, unsigned &q)

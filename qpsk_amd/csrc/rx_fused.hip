@@ -83,7 +83,8 @@ struct Geom {
     static constexpr int WSLOTS = ((WL + WL / (2 * C) + 1 + 31) / 32) * 32 + 16;   /* room for the tightest padding used: 2-symbol lanes */
     static constexpr int DSTRIDE = DR * S + 2;   /* float2 slots per frame row: 16-byte aligned rows (the Costas wave reads two
                                                     symbols per ds_read_b128), 4 dwords (mod 64) apart: lanes hit different bank quads */
-    static constexpr int ZSTRIDE = DR * S + 1;   /* 16-byte records (T.x, T.y, n, -) per Costas row */
+    static constexpr int ZSTRIDE = DR * S + 4;   /* 4-byte records (the phase a step started from) per Costas row: 16-byte
+                                                    aligned rows (four records per write), 4 dwords (mod 64) apart: 16 lanes x 16 bytes on 64 banks */
     static constexpr int MAX_THREADS = SPARE ? 512 : 64 * (MAX_NF + 1);   /* with spares: 3 + 2 FIR waves, 3 retiring ones */
     static_assert(QL == 16 && 64 % QL == 0 && 128 % PAD == 0, "slot arithmetic assumes 16 lanes per frame");
 };
@@ -93,7 +94,6 @@ struct WaveMap {
     static constexpr int QL = QL_, R = R_;
 };
 using GeomNarrow = Geom<16, 4, 4, 1, true>;
-using GeomNarrowAlt = Geom<16, 4, 4, 1, false>;  /* measurement only (QPSK_PIPE_DBG bit 4): the compiler's FIR schedule */
 /* 8 FIR waves, two per SIMD, the serial wave the third on SIMD 0.  Measured and NOT kept: spare waves (3, 3, 2
  * FIR waves per SIMD starve the youngest: 0.394 against 0.371 ms); 7 FIR waves sharing 8 frame groups in turn
  * (no FIR wave twice on the serial wave's SIMD: 0.364 against 0.371 ms, within the run-to-run noise) */
@@ -152,7 +152,7 @@ using namespace pipe;
  * costas_pipe_kernel (ring fed from already decimated symbols in global memory).
  */
 template <class GM>
-__device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const float2 *dring, float4 *zring, int G,
+__device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const float2 *dring, float *zring, int G,
                                             int f0, int lane, int nchunks, int *status)
 {
     QPSK_GEOM_CONSTANTS(GM);
@@ -173,9 +173,9 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
     }
     /* the FIR wave that feeds this lane: 4 frames each; in the mixed workgroup frames 12..15 come two per wave */
     const int gl = lane < G * nbw ? g : 0;
-    const int gw = a.mixed && gl >= 12 ? 3 + (gl - 12) / 2 : gl / FWV;
+    const int gw = a.mixed == 2 ? gl / 2 : a.mixed == 1 && gl >= 12 ? 3 + (gl - 12) / 2 : gl / FWV;
     const float2 *dl = dring + (size_t)(lane < G * nbw ? g : 0) * DSTRIDE;
-    float4 *zl = zring + (size_t)lane * ZSTRIDE;
+    float *zl = zring + (size_t)lane * ZSTRIDE;   /* this lane's records: the phase each symbol's step started from */
     /* one median-of-3 instead of two compare/select pairs when the clamp is the usual min < 0 < max */
     const bool fast_clamp = a.min_freq < 0.0f && a.max_freq > 0.0f;
     float ph = st.phase, fr = st.freq;
@@ -190,20 +190,21 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
             int j = 0;
             if (c == 0) { /* a loaded phase may be -0: first step with the form that is exact there too */
                 Loop s0 = {ph, fr};
-                const float2 z0 = costas_step<true>(s0, lg, dl[slot]);
-                zl[slot] = make_float4(z0.x, z0.y, 0.0f, 0.0f);   /* already de-rotated: quadrant 0 */
+                zl[slot] = ph;
+                costas_step<true>(s0, lg, dl[slot]);
                 ph = s0.phase; fr = s0.freq;
                 j = 1;
-                if (cnt > 1) {   /* the stream below starts on an even symbol (16-byte aligned pair reads) */
+                /* the stream below starts on a symbol number that is a multiple of 4 (16-byte aligned reads of
+                 * symbol pairs and writes of four records) */
+                for (; j < min(4, cnt); j++) {
                     float tx, ty; unsigned qq;
-                    if (fast_clamp) costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + 1], tx, ty, qq);
-                    else costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dl[slot + 1], tx, ty, qq);
-                    zl[slot + 1] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
-                    j = 2;
+                    zl[slot + j] = ph;
+                    if (fast_clamp) costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
+                    else costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
                 }
             }
-            /* the wave only advances the loop and leaves (T, quadrant); de-rotation to z, the slicer and
-             * costas_frame[] happen in the FIR waves' flush */
+            /* the wave only advances the loop and leaves each step's starting phase; de-rotation to z (sin/cos
+             * again, from that phase), the slicer and costas_frame[] happen in the FIR waves' flush */
             /* the next symbol is fetched from LDS one whole step ahead, so the recurrence never waits for
              * the LDS pipe (which the FIR waves keep busy); reading one slot past the chunk is harmless
              * (next slot or the row's padding element) */
@@ -223,8 +224,8 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
                     if (left != 0) {
                         for (int i = 0; i < AG; i++, j++) {
                             float tx, ty; unsigned qq;
+                            zl[slot + j] = ph;
                             costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
-                            zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
                         }
                     }
                 }
@@ -235,8 +236,8 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
                 for (; j < cnt; j++) {
                     const float2 dnext = dl[slot + j + 1];
                     float tx, ty; unsigned qq;
+                    zl[slot + j] = ph;
                     costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
-                    zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
                     dcur = dnext;
                 }
             } else {
@@ -244,8 +245,8 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
                 for (; j < cnt; j++) {
                     const float2 dnext = dl[slot + j + 1];
                     float tx, ty; unsigned qq;
+                    zl[slot + j] = ph;
                     costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
-                    zl[slot + j] = make_float4(tx, ty, __uint_as_float(qq), 0.0f);
                     dcur = dnext;
                 }
             }
@@ -264,13 +265,16 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
 }
 
 /*
- * Flush of one consumed chunk for one frame by its 16 lanes (lane q owns symbols 4q..4q+3 of the chunk):
- * record (T, n) -> z = T (-j)^(n&3) = costas_frame[] (qpsk.c:197), slicer (qpsk.c:74-79), 4 symbols per
- * 32-bit store.
+ * Flush of one consumed chunk for one frame by its lanes (lane q owns symbols R q .. R q + R - 1 of the chunk):
+ * record = the phase the symbol's step started from; with the symbol itself, still in the symbol ring (the slot
+ * is refilled only after this flush, by the same wave), z = symbol x conj(e^{j phase}) = costas_frame[] (qpsk.c:197)
+ * exactly as the step formed it, then the slicer (qpsk.c:74-79), R symbols per store.
  */
 template <class GM, int RW = GM::R>   /* RW symbols per lane: S / RW lanes per frame */
-__device__ __forceinline__ void flush_records(const FusedArgs &a, const float4 *zring, int g, int frame, int q, int chunk)
+__device__ __forceinline__ void flush_records(const FusedArgs &a, const float *zring, const float2 *dring, int g, int frame,
+                                              int q, int chunk)
 {
+    constexpr int DSTRIDE = GM::DSTRIDE;
     constexpr int R = RW, S = GM::S, ZSTRIDE = GM::ZSTRIDE;
     static_assert(R == 2 || R == 4, "packs 2 or 4 symbols per store");
     const int nbw = a.nbw, N = a.nsym;
@@ -283,8 +287,9 @@ __device__ __forceinline__ void flush_records(const FusedArgs &a, const float4 *
         uint32_t packed = 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            const float4 tq = zring[(size_t)row * ZSTRIDE + slot + R * q + r];
-            z[r] = apply_quadrant(tq.x, tq.y, __float_as_uint(tq.z));
+            const float ph = zring[(size_t)row * ZSTRIDE + slot + R * q + r];
+            const float2 d = dring[(size_t)g * DSTRIDE + slot + R * q + r];
+            z[r] = (sym0 + R * q + r == 0) ? derotate<true>(ph, d) : derotate<false>(ph, d);
             packed |= (uint32_t)slicer(z[r]) << (8 * r);
         }
         if (a.sym) {
@@ -322,7 +327,7 @@ costas_pipe_kernel(FusedArgs a, int *status)
     const int NF = (int)blockDim.x / 64 - 1;
     const int G = NF * FWV;
     float2 *dring = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));     /* [G][DSTRIDE] */
-    float4 *zring = reinterpret_cast<float4 *>(dring + (size_t)G * DSTRIDE);  /* [G][ZSTRIDE] */
+    float *zring = reinterpret_cast<float *>(dring + (size_t)G * DSTRIDE);  /* [G][ZSTRIDE] */
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = a.nsym;
     const int f0 = blockIdx.x * G;
@@ -355,7 +360,7 @@ costas_pipe_kernel(FusedArgs a, int *status)
             ok = wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag);
             if (!ok) break;
             for (; flushed < c - DR + 1; flushed++)
-                if (fvalid) flush_records<GM>(a, zring, g, frame, q, flushed);
+                if (fvalid) flush_records<GM>(a, zring, dring, g, frame, q, flushed);
         }
         float2 *dw = dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q;
 #pragma unroll
@@ -380,7 +385,7 @@ costas_pipe_kernel(FusedArgs a, int *status)
         ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
         if (ok)
             for (; flushed < nchunks; flushed++)
-                if (fvalid) flush_records<GM>(a, zring, g, frame, q, flushed);
+                if (fvalid) flush_records<GM>(a, zring, dring, g, frame, q, flushed);
     }
     if (!ok && lane == 0) atomicExch(status, 1);
 }
@@ -398,12 +403,12 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     const bool spares = GM::SPARE && !(a.dbg & 4);
     const int nwaves = (int)blockDim.x / 64;
     const bool mixed = a.mixed != 0;                                        /* 16 frames, two lane mappings (see the FIR waves) */
-    const int NF = mixed ? 4 : spares ? (nwaves - 1) - (nwaves - 1) / 4 : nwaves - 1;   /* frame groups */
-    const int G = NF * FWV;                                                 /* frames of the workgroup */
+    const int nfir = spares ? (nwaves - 1) - (nwaves - 1) / 4 : nwaves - 1;   /* FIR waves unless mixed */
+    const int G = a.mixed == 1 ? 4 * FWV : a.mixed == 2 ? 2 * nfir : nfir * FWV;   /* frames of the workgroup */
     float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));   /* [G][WSLOTS] */
     float2 *dring = win + (size_t)G * WSLOTS;                              /* [G][DSTRIDE] */
-    float4 *zring = reinterpret_cast<float4 *>(dring + (size_t)G * DSTRIDE); /* [G*nbw][ZSTRIDE] records (T.x, T.y, n, -):
-                                                                               T = d*(C - jS), quadrant = n & 3, see costas_step_t */
+    float *zring = reinterpret_cast<float *>(dring + (size_t)G * DSTRIDE);   /* [G*nbw][ZSTRIDE] records: the phase each
+                                                                               symbol's step started from, see flush_records */
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   /* scalar: per-wave frame pointers stay in SGPRs */
@@ -435,7 +440,14 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
      *     its frames outright.  Bit-exact like the plain layout, and no faster (see the launcher). */
     int w, gbase, rslot;          /* FIR wave index, first frame slot, its ready[] counter */
     bool half = false;
-    if (mixed) {
+    if (a.mixed == 2) {   /* several loops per frame: every FIR wave takes two frames, 2 symbols per lane (the flush
+                             does sin/cos once per loop and symbol, so the frames are spread over more waves) */
+        if (spares && (wave & 3) == 0) return;
+        w = spares ? wave - 1 - wave / 4 : wave - 1;
+        half = true;
+        gbase = 2 * w;
+        rslot = w;
+    } else if (mixed) {
         if (wave >= 4 && wave <= 5) return;
         half = wave >= 6;
         w = half ? wave - 3 : wave - 1;
@@ -535,36 +547,16 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     auto tick = [](int) {};
 #endif
 
-    /* Who turns a group's finished records into symbols.  Normally the group's own FIR wave.  In the full narrow
-     * workgroup FIR waves 0 and 3 share SIMD 1 and set the pace (the younger one filters at 9.2 k cycles per
-     * chunk against 6.3 k for the waves alone on SIMDs 2 and 3, which then wait ~5 k for it): there the two lone
-     * waves flush for the pair as well.  (Raising the younger wave's priority only swaps which of the two is
-     * late: 0.2001 against 0.1989 ms.)  In the full wide workgroup the oldest wave of SIMDs 1-3 (FIR waves 0-2)
-     * has the slack and the younger ones, above all the two beside the serial wave, set the pace: waves 0-2 flush
-     * for everybody. */
-    /* In the mixed workgroup the 2-symbol waves only filter: the lone 4-symbol wave of SIMD 1 flushes their four
-     * frames (12..15) with its own mapping, the other two 4-symbol waves flush their own. */
-    const bool offload_narrow = !mixed && GM::SPARE && spares && NF == 4 && !(a.dbg & 64);
-    const bool offload_wide = !GM::SPARE && NF == 8 && !(a.dbg & 64);
-    int fbase[3] = {gbase, gbase, gbase};   /* first frame slot of each set of FWV frames this wave flushes */
-    int nflush = 1;
-    if (mixed) {
-        if (half) nflush = 0;
-        else if (w == 0) { nflush = 2; fbase[1] = 12; }
-    } else if (offload_narrow) {
-        if (w == 1) { nflush = 2; fbase[1] = 3 * FWV; }
-        else if (w == 2) { nflush = 2; fbase[1] = 0; }
-        else nflush = 0;
-    } else if (offload_wide) {
-        if (w == 0) { nflush = 3; fbase[1] = 4 * FWV; fbase[2] = 7 * FWV; }
-        else if (w == 1) { nflush = 3; fbase[1] = 5 * FWV; fbase[2] = 3 * FWV; }
-        else if (w == 2) { nflush = 2; fbase[1] = 6 * FWV; }
-        else nflush = 0;
-    }
+    /* Every wave turns its own frames' records into symbols: the flush needs the symbols themselves, and they
+     * stay in the ring only until their owner refills the slot -- which it does right after this flush.  (With the
+     * (T, quadrant) records of the earlier design any wave could flush for any other, and the waves with slack did;
+     * the phase records take 8 bytes per step off the serial wave's LDS writes instead.) */
+    const int fbase[1] = {gbase};
+    const int nflush = 1;
     auto flush_chunk = [&](int chunk) {
         for (int i = 0; i < nflush; i++) {
             const int g2 = fbase[i] + fl, fr2 = f0 + g2;
-            if (fr2 < a.nframes) flush_records<GM, R>(a, zring, g2, fr2, q, chunk);
+            if (fr2 < a.nframes) flush_records<GM, R>(a, zring, dring, g2, fr2, q, chunk);
         }
     };
 
@@ -609,8 +601,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
          * live for R consecutive blocks */
         static_assert(C == 8 && (R == 4 || R == 2), "the step below is written for C = 8 and R = 2 or 4");
         if constexpr (!GM::PINNED) {
-            /* the compiler's own schedule of the same sum, kept for A/B runs (QPSK_PIPE_DBG bit 4): config 2
-             * 0.2148 ms against 0.2088 ms with the pinned order below [measured, same process] */
+            /* the compiler's own schedule of the same sum (a Geom with PINNED = false; no longer instantiated):
+             * config 2 ran 0.2148 ms with it against 0.2088 ms with the pinned order below [measured, same process] */
             if (!(a.dbg & 1)) {
                 float tgc[R][C];
 #pragma unroll
@@ -766,7 +758,7 @@ template <class GM>
 static size_t lds_bytes_of(int NF, int nbw)
 {
     const size_t G = (size_t)frames_of<GM>(NF);
-    size_t b = sizeof(Smem) + sizeof(float2) * (G * GM::WSLOTS + G * GM::DSTRIDE) + sizeof(float4) * G * nbw * GM::ZSTRIDE;
+    size_t b = sizeof(Smem) + sizeof(float2) * (G * GM::WSLOTS + G * GM::DSTRIDE) + sizeof(float) * G * nbw * GM::ZSTRIDE;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -782,26 +774,26 @@ int pipe_max_nf(bool wide) { return wide ? GeomWide::MAX_NF : GeomNarrow::MAX_NF
 int launch_rx_fused_pipe(const FusedArgs &a0, int NF, bool wide, int *status, hipStream_t s)
 {
     FusedArgs a = a0;
-    /* measurement knob (QPSK_PIPE_DBG bit 7): the full narrow workgroup with two lane mappings, see the kernel.
-     * Config 2 runs 0.202-0.210 ms with it and 0.200-0.202 ms without [same process]: with the FIR waves alone the
-     * kernel takes 0.18 ms, with the loop alone 0.185 ms, so the SIMD that carries two FIR waves is not what
-     * separates the 0.20 ms from either -- NOT the default */
-    a.mixed = !wide && NF == GeomNarrow::MAX_NF && (a.dbg & 128) && !(a.dbg & 4);
+    /* the full narrow workgroup runs with two lane mappings (see the kernel): no SIMD carries two four-frame
+     * units, every FIR wave has slack and the kernel follows the loop.  QPSK_PIPE_DBG bit 7 = the plain layout
+     * (4 FIR waves + 1 spare) for A/B runs */
+    a.mixed = !wide && NF == GeomNarrow::MAX_NF && !(a.dbg & (128 | 4));
+    /* several loops per frame (bandwidth sweeps): the flush costs a sin/cos per loop and symbol, so the frames go
+     * two to a FIR wave (2 symbols per lane) instead of four */
+    if (!wide && !a.mixed && a.nbw > 1 && NF <= 3 && !(a.dbg & (128 | 4))) a.mixed = 2;
     const int G = pipe_frames(NF, wide);
     const int blocks = (a.nframes + G - 1) / G;
     const size_t lds = pipe_lds_bytes(NF, a.nbw, wide);
     if (NF < 1 || NF > pipe_max_nf(wide) || lds > (size_t)MAX_LDS_BYTES || G * a.nbw > 64) return (int)hipErrorInvalidValue;
     /* hardware waves of a workgroup with NF FIR waves: with spares, FIR wave k is hardware wave k + 1 + k/3 */
-    auto nwaves = [&](int spare) { return (spare && !(a.dbg & 4)) ? NF + 1 + (NF - 1) / 3 : NF + 1; };
+    const int nfir = a.mixed == 2 ? 2 * NF : NF;
+    auto nwaves = [&](int spare) { return (spare && !(a.dbg & 4)) ? nfir + 1 + (nfir - 1) / 3 : nfir + 1; };
     if (wide) {
         hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomWide>, dim3(blocks), dim3(64 * nwaves(GeomWide::SPARE)), lds, s, a, status);
     } else {
         /* mixed: hardware waves 0 (loop), 1-3 (4 frames each), 4-5 (retire), 6-7 (2 frames each) */
-        const dim3 threads(a.mixed ? 512 : 64 * nwaves(GeomNarrow::SPARE));
-        if (a.dbg & 16)   /* measurement knob (QPSK_PIPE_DBG bit 4): the other FIR-step schedule */
-            hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrowAlt>, dim3(blocks), threads, lds, s, a, status);
-        else
-            hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrow>, dim3(blocks), threads, lds, s, a, status);
+        const dim3 threads(a.mixed == 1 ? 512 : 64 * nwaves(GeomNarrow::SPARE));
+        hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrow>, dim3(blocks), threads, lds, s, a, status);
     }
     hipError_t e = hipGetLastError();
     return (int)e;
@@ -812,7 +804,7 @@ int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
     using GM = GeomNarrow;
     const int G = NF * GM::FWV;
     const int blocks = (a.nframes + G - 1) / G;
-    const size_t lds = sizeof(Smem) + sizeof(float2) * (size_t)G * GM::DSTRIDE + sizeof(float4) * (size_t)G * GM::ZSTRIDE;
+    const size_t lds = sizeof(Smem) + sizeof(float2) * (size_t)G * GM::DSTRIDE + sizeof(float) * (size_t)G * GM::ZSTRIDE;
     hipLaunchKernelGGL(costas_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1)), lds, s, a, status);
     return (int)hipGetLastError();
 }
@@ -823,9 +815,6 @@ int prepare_pipe_kernel(void)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomWide>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomNarrowAlt>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomNarrow>),
