@@ -3,20 +3,23 @@
  * instruction stream, for the serial wave of rx_fused_pipe_kernel.
  *
  * Why assembly: the recurrence runs in ONE wave per workgroup and that wave is strictly in order.  Measured
- * on MI355X with timing-only variants of this stream inside the kernel: the lone wave issues
- * one VALU instruction per ~5.2 cycles -- the step is ISSUE bound, an instruction more or less is ~5.5 cycles,
- * while taking dependent fp32 operations off the critical path changes nothing; only the five fp64 operations
- * phase -> range reduction -> x^2, each waiting ~8 cycles for the one before, leave issue slots empty.  Every
- * LDS instruction costs the wave 12-14 cycles of issue, a not-taken branch on a VALU compare ~10.  The
- * compiler's version of the step ran ~355 cycles.  What this stream does about it:
+ * on MI355X with timing-only variants of this stream inside the kernel (tools/ab_libs.py): the
+ * step is ISSUE bound.  The lone wave issues a VALU instruction every 4 cycles and loses 4 more wherever an
+ * instruction needs the result of the one right before it (5.2 cycles per instruction on average: one more or
+ * less is ~5.5, while taking dependent operations off the critical path without removing such adjacencies changes
+ * nothing); an LDS instruction costs it 15-25 cycles almost regardless of its size (16 -> 12 -> 4 bytes per step:
+ * -2.4 %, then -1 %; one write per 16 steps instead of one per step: -8 %); a not-taken branch on a VALU compare
+ * ~10.  The compiler's version of the step ran ~355 cycles.  What this stream does about it:
  *   - 28 VALU instructions per step;
- *   - the tail of step k that nothing in step k+1 waits for -- its record write, the frequency clamp, the
- *     exact-zero test, the 2*pi test -- is issued in the empty slots of step k+1's fp64 head;
- *   - the 2*pi wrap is out of line AND late: step k+1 starts from the unwrapped phase, the branch sits four
- *     instructions after its compare, and the rare wrap block corrects the phase and redoes the head;
- *   - LDS traffic is 1.5 instructions per step: two symbols per ds_read_b128 (fetched two steps ahead into
- *     alternating register sets), one record (T.x, T.y, n) per ds_write_b96 into a 16-byte slot (an LDS write
- *     costs the wave ~3.5 cycles per dword: 12 bytes instead of 16 took 2.4 % off the loop);
+ *   - the only thing a step leaves behind is the PHASE it started from (the FIR waves' flush redoes sin/cos and
+ *     the rotation from it, bit for bit the same operations): four steps' phases sit in v140..v143 and go to LDS
+ *     in one ds_write_b128, so the wave issues 0.75 LDS instructions per step (two symbols per ds_read_b128,
+ *     fetched two steps ahead into alternating register sets) instead of 1.5;
+ *   - what nothing in step k+1 waits for -- step k's frequency clamp and exact-zero test, the 2*pi test of the
+ *     phase it produced -- is issued in the empty slots between the five dependent fp64 operations of step
+ *     k+1's head;
+ *   - the 2*pi wrap is out of line AND late: step k+1 starts from the unwrapped phase, the branch sits at the end
+ *     of the head, and the rare wrap block corrects the phase where it stands and redoes the head;
  *   - groups of 16 steps: the per-group bookkeeping (state snapshot, flag test, taken loop branch) costs
  *     ~60 cycles;
  *   - the exact-zero test of the detector input is a running min over the group; with zeros out of the way
@@ -34,19 +37,21 @@
  * min_freq < 0 < max_freq, where it equals costas_loop.c:69-74).  The parity tests compare the kernel with
  * the oracle bit for bit.
  *
- * One call runs `groups` groups of COSTAS_ASM_GROUP steps; the first symbol must be an EVEN one (16-byte
- * aligned pairs).  Cases the stream does not handle set a flag, and the group they occur in is abandoned with
- * the loop state restored to the group's start; the caller redoes that group with costas_step_t() and continues:
+ * One call runs `groups` groups of COSTAS_ASM_GROUP steps; the first symbol's number must be a multiple of 4
+ * (16-byte aligned symbol pairs and record quads).  Cases the stream does not handle set a flag, and the group
+ * they occur in is abandoned with the loop state restored to the group's start (its records are then rewritten
+ * too); the caller redoes that group with costas_step_t() and continues:
  *     min(|T.x|, |T.y|) == 0   (the detector's sgn(0) = -1 asymmetry, see costas_step_t)
  *     a phase still outside [-2pi, 2pi] after ONE wrap (clamp wider than +-2pi, huge amplitudes).
  *
- * Registers: v[100:139] are scratch owned by the block (clobbered; low enough for a kernel built for three
+ * Registers: v[100:143] are scratch owned by the block (clobbered; low enough for a kernel built for three
  * waves per SIMD, i.e. at most 168 VGPRs):
  *   100:101 x / d*C      102:103 beta*d, alpha*d   104:105 n / x3 / d*S     106:107 xr / d
  *   108:109 x2 / s       110:111 cos chain (v110 = C)   112:113 sin chain (v112 = S)
- *   114:117 the record: T.x, T.y, then the magic sum (v116 bits 1:0 = quadrant, v117 don't care)
+ *   114:115 T            116:117 the magic sum of the range reduction
  *   118 f2   119 p+f2    120:123, 136:139 two pairs of decimated symbols   126 running min
- *   127 2pi hi   128:129 +-2pi   130,131 group-start phase/freq    132..135 phase/freq ping-pong
+ *   127 2pi hi   128:129 +-2pi   130,131 group-start phase/freq    133, 135 frequency ping-pong
+ *   140:143 the phases of four consecutive steps (step k in v140 + k % 4) = their records
  */
 #ifndef QPSK_COSTAS_ASM_H
 #define QPSK_COSTAS_ASM_H

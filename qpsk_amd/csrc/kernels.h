@@ -17,14 +17,14 @@ struct FusedArgs {
     const float2 *x;        /* [nframes][frame_size] */
     int nframes, frame_size, cycles, nsym;
     int G, S;               /* frames per workgroup, symbols per chunk */
-    int mixed;              /* rx_fused_pipe_kernel, set by its launcher: 16 frames per workgroup, the last four filtered by
-                               two waves with 2 symbols per lane (see the kernel) */
+    int mixed;              /* rx_fused_pipe_kernel, set by its launcher: 0 = every FIR wave filters 4 frames, 4 symbols per
+                               lane; 1 = 16 frames per workgroup, the last four by two waves of 2 frames with 2 symbols
+                               per lane; 2 = every FIR wave 2 frames with 2 symbols per lane (see the kernel) */
     const int32_t *index;   /* [nframes] or NULL -> fixed_index */
     int fixed_index;
     int dbg;                /* measurement only (QPSK_PIPE_DBG): 1 skip FIR arithmetic, 2 skip the Costas recurrence,
-                               4 no spare waves, 8 C++ Costas step, 16 compiler-scheduled FIR step, 32 print the cycle
-                               accounting of workgroup 0's FIR waves (profile build), 64 no flush offload, 128 two lane
-                               mappings in the full narrow workgroup */
+                               4 no spare waves, 8 C++ Costas step, 32 print the cycle accounting of workgroup 0's FIR
+                               waves (profile build), 128 one lane mapping for all FIR waves (the plain layout) */
     const float2 *dsrc;     /* costas_pipe_kernel only: decimated symbols, rows dstride symbols apart */
     int dstride;
     /* costas_pipe_kernel, streaming mode (qpsk.c:186-191): once symbol i of a row has been taken, its slot is

@@ -12,12 +12,16 @@
  *     2048 x (instructions per step) x 5 cycles however many CUs idle.
  * So each workgroup is a producer/consumer pipeline in LDS:
  *   wave 0           the Costas recurrence (costas_asm.h), one lane per (frame, loop); it never waits
- *                    for HBM and leaves 16-byte records (T.x, T.y, n, -) in an LDS ring;
- *   FIR waves        each owns 4 frames outright (loads, history, filter, and the flush of its frames'
- *                    records: de-rotation to costas_frame[], slicer, coalesced stores), so FIR waves
- *                    never synchronise with each other, only with wave 0 through two monotonic
- *                    counters in LDS (bounded spins; a timeout is reported through *status);
- *   wave 4           (only when there are 4 FIR waves) exits at once, so that wave 0 does not share a SIMD.
+ *                    for HBM and leaves one 4-byte record per step in an LDS ring: the phase the step
+ *                    started from (four steps per LDS write);
+ *   FIR waves        each owns its frames outright (loads, history, filter, and the flush of their
+ *                    records: sin/cos of the recorded phase again, de-rotation of the symbol -- still in the
+ *                    symbol ring -- to costas_frame[], slicer, coalesced stores), so FIR waves never
+ *                    synchronise with each other, only with wave 0 through two monotonic counters in LDS
+ *                    (bounded spins; a timeout is reported through *status);
+ *   spare waves      hardware waves that would land on wave 0's SIMD exit at once.
+ * A full workgroup (16 frames) has three FIR waves of 4 frames (4 symbols per lane) and two of 2 frames
+ * (2 symbols per lane): 1, 1.5, 1.5 filter units on the three SIMDs the serial wave leaves free.
  *
  * FIR wave layout (numbers of the narrow geometry, Geom<16,4,4,1>; the wide
  * one, Geom<16,2,8,0>, halves R, S and the window, see struct Geom): lane =
@@ -53,18 +57,15 @@ constexpr int MAX_WAVES = 8;     /* FIR waves of the widest geometry */
 constexpr int SPIN_LIMIT = 1 << 24;
 
 /*
- * Two geometries of the same pipeline, chosen by the host from the batch size.  A SIMD executes one wave's VALU
- * instruction per 4 cycles, oldest wave first; the FIR step issues at 4.1 cycles per packed instruction from
- * registers and 6.2 with its LDS reads (tools/ubench_fir.hip), so one FIR wave leaves a third of its SIMD idle and
- * two saturate it.  The LDS (window + rings per frame) decides how many frames a workgroup holds:
- *   Geom<16, 4>  lane = (frame of 4) x (q of 16), 4 symbols per lane: chunks of 64 symbols, 8.6 KB of LDS per
- *                frame, 4 FIR waves = 16 frames per workgroup.  A batch of up to 16 frames per CU (config 2:
- *                4096 frames) is bounded by the recurrence, not by the FIR: the serial wave gets a SIMD of
- *                its own (a spare wave retires at once) and three SIMDs filter.
- *   Geom<16, 2>  2 symbols per lane: chunks of 32 symbols, 5.0 KB per frame, 8 FIR waves = 32 frames per
- *                workgroup (two FIR waves per SIMD), the serial wave carries 32 loops for the price of 16.
- *                11 % more FIR instructions per symbol (135 window reads per 2 symbols instead of 151 per 4).
- *                Bigger batches (config 4: 8192 frames per GPU) are bounded by the FIR waves.
+ * Geometry of a workgroup.  The LDS (window + rings per frame) decides how many frames it holds:
+ *   Geom<16, 4>  "narrow", the one the host uses: chunks of 64 symbols, 7.3 KB of LDS per frame, 16 frames per
+ *                workgroup; the serial wave has a SIMD of its own (spare waves retire at once) and three SIMDs
+ *                filter.  Lane mappings of its FIR waves: (frame of 4) x (q of 16) with 4 symbols per lane, or
+ *                (frame of 2) x (q of 32) with 2 symbols per lane -- both in one workgroup when it is full (see
+ *                the kernel).  Batches above 16 frames per CU run in rounds of such workgroups.
+ *   Geom<16, 2>  "wide" (QPSK_PIPE_WIDE=1 only): chunks of 32 symbols, 32 frames and 8 FIR waves per workgroup, two of
+ *                them beside the serial wave.  It was the faster choice for 8192 frames per GPU while the serial
+ *                wave wrote a 16-byte record every step; with phase records the narrow rounds are (api.cpp).
  */
 template <int QL_, int R_, int MAX_NF_, int SPARE_, bool PINNED_>
 struct Geom {

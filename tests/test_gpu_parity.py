@@ -151,7 +151,8 @@ def test_pipeline_geometries_agree(oracle, monkeypatch, L, mode):
             got = m.rx_batch(x[:33], want_costas=False)
             m.sync()
             assert bits_equal(cpu(got["sym"]), want["sym"][:33]) and bits_equal(cpu(got["freq"]), want["freq"][:33])
-    # the measurement variant with two lane mappings in one workgroup (16 frames: 12 at 4 symbols per lane, 4 at 2)
+    # nf = 4 above ran with two lane mappings in one workgroup (16 frames: 12 at 4 symbols per lane, 4 at 2);
+    # the A/B variant with one mapping for all four FIR waves
     monkeypatch.setenv("QPSK_PIPE_WIDE", "0")
     monkeypatch.setenv("QPSK_PIPE_NF", "4")
     monkeypatch.setenv("QPSK_PIPE_DBG", "128")
