@@ -286,13 +286,34 @@ __device__ __forceinline__ void flush_records(const FusedArgs &a, const float *z
         const size_t o = ((size_t)frame * nbw + b) * N + sym0 + R * q;
         float2 z[R];
         uint32_t packed = 0;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const float ph = zring[(size_t)row * ZSTRIDE + slot + R * q + r];
-            const float2 d = dring[(size_t)g * DSTRIDE + slot + R * q + r];
-            z[r] = (sym0 + R * q + r == 0) ? derotate<true>(ph, d) : derotate<false>(ph, d);
-            packed |= (uint32_t)slicer(z[r]) << (8 * r);
+        /* the lane's R records and R symbols: rows are 16-byte aligned and R q is a multiple of R, so they come
+         * as whole 8- or 16-byte LDS reads */
+        float phv[R];
+        float2 dv[R];
+        {
+            const float *zp = zring + (size_t)row * ZSTRIDE + slot + R * q;
+            const float2 *dp = dring + (size_t)g * DSTRIDE + slot + R * q;
+            if constexpr (R == 4) {
+                const float4 p4 = *reinterpret_cast<const float4 *>(zp);
+                const float4 da = reinterpret_cast<const float4 *>(dp)[0], db = reinterpret_cast<const float4 *>(dp)[1];
+                phv[0] = p4.x; phv[1] = p4.y; phv[2] = p4.z; phv[3] = p4.w;
+                dv[0] = make_float2(da.x, da.y); dv[1] = make_float2(da.z, da.w);
+                dv[2] = make_float2(db.x, db.y); dv[3] = make_float2(db.z, db.w);
+            } else {
+                const float2 p2 = *reinterpret_cast<const float2 *>(zp);
+                const float4 da = *reinterpret_cast<const float4 *>(dp);
+                phv[0] = p2.x; phv[1] = p2.y;
+                dv[0] = make_float2(da.x, da.y); dv[1] = make_float2(da.z, da.w);
+            }
         }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            z[r] = derotate<false>(phv[r], dv[r]);
+        if (chunk == 0 && q == 0)   /* the frame's first symbol: its phase may be a loaded -0 */
+            z[0] = derotate<true>(phv[0], dv[0]);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            packed |= (uint32_t)slicer(z[r]) << (8 * r);
         if (a.sym) {
             if (R * q + R <= cnt && ((N | sym0) & (R - 1)) == 0) {   /* o is a multiple of R: one aligned store */
                 if constexpr (R == 4) *reinterpret_cast<uint32_t *>(a.sym + o) = packed;
