@@ -4,11 +4,15 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
 
 One "step" = one pass of the fused RRC-FIR + Costas + slicer kernel (qpsk_rx_batch, fixed timing
-offset: BASELINE.json configs[1], "Batch 4096 frames x 16384 complex samples, RRC FIR + Costas on 1
-MI355X") over one batch of synthetic frames that is already resident in HBM.  With N > 1 the driver
-starts one process per GPU (torch.distributed.run); every rank owns its own independent batch of the
-same size (frames are independent: no data-path collective); the only communication is
-the barrier and the max-over-ranks of the elapsed time.
+offset) over one batch of synthetic frames that is already resident in HBM.
+  N = 1: BASELINE.json configs[1], "Batch 4096 frames x 16384 complex samples, RRC FIR + Costas on 1 MI355X".
+  N > 1: BASELINE.json configs[3], "65536 frames x 16384 samples sharded across 8 MI355X": 8192 frames per
+         GPU, one process per GPU, every rank demodulating its own contiguous shard of the job's N x 8192
+         independent frames (no data-path collective); the only communication is the barrier
+         and the max-over-ranks of the elapsed time.
+Ranks: under torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE in the environment) this process IS one rank.
+Started plainly with --gpus N > 1, it starts the N ranks itself as child processes -- before anything in
+this process has touched the GPU -- relays rank 0's JSON line and exits non-zero if any rank failed.
 
 Prints ONE JSON line on rank 0 (see the keys at the bottom).
 """
@@ -27,6 +31,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FS, RS, L = 19200.0, 2400.0, 16384        # 2400 baud, 8x oversample, 16384 complex samples per frame
 CYCLES = 8
 FIXED_INDEX = 6                            # TX RRC (63) + RX RRC (63) group delay = 126 = 15*8 + 6
+FRAMES_1GPU = 4096                         # BASELINE configs[1]
+FRAMES_PER_GPU_SHARDED = 8192              # BASELINE configs[3]: 65536 frames over 8 GPUs
 HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 BYTES_PER_SAMPLE = 8                       # one complex float read per input sample
 
@@ -93,6 +99,32 @@ def cpu_baseline(x_host, taps):
     return out
 
 
+def launch_ranks(n, argv):
+    """Start n ranks of this script as child processes (plain subprocess, never an exec of a process that has
+    initialised the GPU), relay rank 0's single JSON line; returns the exit status (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: ranks failed: %s" % bad, file=sys.stderr)
+        return 1
+    return 0
+
+
 def note(msg):
     if os.environ.get("QPSK_BENCH_VERBOSE"):
         print("[bench] " + msg, file=sys.stderr, flush=True)
@@ -101,11 +133,12 @@ def note(msg):
 def main():
     global L
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of the job (default: WORLD_SIZE, else 1)")
     # a step is 0.2 ms: 20 steps are over before the clocks have settled (0.210 ms/step against 0.198 over 200)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step (config 2: 4096)")
+    ap.add_argument("--frames", type=int, default=None,
+                    help="frames per GPU per step (default: 4096 = config 2 on one GPU, 8192 = config 4's per-GPU share on several)")
     ap.add_argument("--cpu-frames", type=int, default=2048,
                     help="frames of the CPU baseline sample (0 = skip); 2048 = half a batch, ~12 s of the reference on one core")
     ap.add_argument("--no-parity", action="store_true")
@@ -113,16 +146,39 @@ def main():
     args = ap.parse_args()
     L = args.frame_size
 
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(env_world) if env_world else 1
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        # nothing has touched the GPU yet (no torch, no libqpsk_hip): start the ranks as children
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, env_world))
+    if args.frames is None:
+        args.frames = FRAMES_1GPU if args.gpus == 1 else FRAMES_PER_GPU_SHARDED
+    # ONE line on stdout: whatever the libraries of a rank print there (gloo announces its connections) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import qpsk_amd
 
-    from qpsk_amd.shard import env_rank_world, init_distributed, max_over_ranks, shard_range
+    from qpsk_amd.shard import (env_rank_world, init_distributed, local_device, max_over_ranks, shard_range,
+                                sum_over_ranks)
     rank, local, world = env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libqpsk_hip has no CPU path")
+    ndev = torch.cuda.device_count()
+    local = local_device(local, ndev)             # one GPU per rank; ranks share only when the box has fewer GPUs
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = init_distributed("nccl", dev)          # nccl == RCCL on ROCm; None when WORLD_SIZE == 1
+    # nccl == RCCL on ROCm (one GPU per rank); ranks that share a GPU (rehearsal on a smaller box) meet over gloo
+    shared = world > ndev
+    dist = init_distributed("gloo" if shared else "nccl", None if shared else dev)   # None when WORLD_SIZE == 1
+    rdev = None if shared else dev
     if not os.path.exists(qpsk_amd.lib_path()):
         if rank == 0:
             qpsk_amd.build()
@@ -162,8 +218,10 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, rdev)
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    m.sync()      # raises if a kernel's in-LDS pipeline gave up (bounded spins): such a run has no valid timing
+    joined = int(round(sum_over_ranks(1, dist, rdev)))      # ranks that really took part
 
     # cross-check, outside the timed region: one event pair per launch (each pair adds its own ~2 us)
     nev = min(args.steps, 50)
@@ -195,23 +253,24 @@ def main():
             traffic = None
     res = {
         "metric": "complex Msamples/s demodulated + % HBM roofline, 2400-baud RRC+Costas path",
-        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "Msamples/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "batch %d frames x %d complex samples per GPU, 2400 baud, 8x oversample, fused RRC FIR + Costas + slicer, fixed timing offset %d (%s)" % (
                        F, L, FIXED_INDEX, "BASELINE configs[1]" if (F, L) == (4096, 16384) else
                        "BASELINE configs[3] per-GPU share" if (F, L) == (8192, 16384) else "non-BASELINE shape"),
-                   "frames_per_gpu": F, "frame_size": L, "fs": FS, "rs": RS, "loop_bw": "TAU/100", "sharding": "independent frames per GPU, no collective"},
+                   "frames_per_gpu": F, "frames_total": world * F, "gpus_visible_per_rank_box": ndev, "frame_size": L, "fs": FS, "rs": RS, "loop_bw": "TAU/100", "sharding": "independent frames per GPU, no collective"},
         "roofline": {"bound": "hbm", "kernel": "rx_fused_pipe_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
                      "kernel_ms_event_pair_per_launch": kernel_ms_pairs,
                      "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * F * L},
     }
-    if world == 1:
+    if world == 1:          # the CPU baseline is reported at N = 1 only
         ncpu = min(args.cpu_frames, F)
         if ncpu > 0:
             xh = x[:ncpu].cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(xh, m.taps)
+    if True:                # parity gate of the same run (rank 0's shard)
         if not args.no_parity:
             from oracle.pyoracle import Oracle, TIMING_FIXED
             npar = min(256, F)
@@ -222,7 +281,7 @@ def main():
                              "freq_bit_mismatches": int(np.sum(gf.view(np.uint32) != want["freq"].view(np.uint32))),
                              "phase_bit_mismatches": int(np.sum(gp.view(np.uint32) != want["phase"].view(np.uint32))),
                              "mean_freq_hz": float(np.mean(gf.astype(np.float64) * RS / (2 * np.pi)))}
-    print(json.dumps(res))
+    print(json.dumps(res), file=real_stdout, flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

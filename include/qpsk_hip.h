@@ -46,7 +46,11 @@ typedef enum {
     QPSK_ERR_ARG = -2,       /* null pointer, non-positive size, frame_size % cycles != 0, ... */
     QPSK_ERR_HIP = -3,       /* a HIP runtime call or a kernel launch failed */
     QPSK_ERR_ALLOC = -4,
-    QPSK_ERR_STATE = -5      /* call sequence error (e.g. stream call on a context made for 0 streams) */
+    QPSK_ERR_STATE = -5,     /* call sequence error (e.g. stream call on a context made for 0 streams) */
+    QPSK_ERR_RANGE = -6      /* a Costas loop phase left the range the bounded 2 pi wrap covers (|phase| > ~25,000 rad:
+                                input some 10^5 times the modem's working amplitude, or non-finite).  The reference's
+                                phase_wrap() (costas_loop.c:61-67) spins |phase| / 2 pi times there and never returns once
+                                |phase| >= 2^27; a GPU wave must not, so the call fails instead */
 } qpsk_status;
 
 /* How the decimation offset ("index", qpsk.c:105,173-180,190) is chosen. */
@@ -86,6 +90,12 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
 void qpsk_ctx_destroy(qpsk_ctx *ctx);
 int qpsk_ctx_sync(qpsk_ctx *ctx);
 int qpsk_ctx_set_stream(qpsk_ctx *ctx, void *stream);
+/* Kernel-geometry selection for tests and measurements (never needed for results: every geometry computes the same
+ * bits).  Names: "QPSK_PIPE_V", "QPSK_PIPE_G", "QPSK_PIPE_NF", "QPSK_PIPE_WIDE", "QPSK_PIPE_DBG" (layout bits), "QPSK_FUSED_G", "QPSK_FUSED_S",
+ * "QPSK_FUSED_LDS", "QPSK_FUSED_GENERIC", "QPSK_HIST_GENERIC"; value < 0 = back to the library's own choice.
+ * Environment variables of the same names are read once, by qpsk_ctx_create(), as the context's initial values;
+ * no other call reads the environment, and none of them can change a result. */
+int qpsk_ctx_set_tuning(qpsk_ctx *ctx, const char *name, int value);
 int qpsk_ctx_cycles(const qpsk_ctx *ctx);   /* CYCLES */
 int qpsk_ctx_nsym(const qpsk_ctx *ctx);     /* FRAME_SIZE / CYCLES */
 

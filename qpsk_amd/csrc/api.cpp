@@ -52,8 +52,40 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+/*
+ * Tuning: choices that select WHICH kernel geometry computes a result, never the result (every geometry is bit-exact
+ * against the oracle; tests/test_gpu_parity.py runs them all).  -1 = the library's own choice.  The QPSK_* environment
+ * variables of the same names are read ONCE, in qpsk_ctx_create(); qpsk_ctx_set_tuning() overrides them per context.
+ * Nothing on a call path reads the environment.
+ */
+struct Tuning {
+    int fused_g = -1, fused_s = -1, fused_lds = -1;   /* generic chunked kernel: frames per workgroup, symbols per chunk, LDS budget */
+    int generic = -1;                                 /* 1: the barrier-synchronised generic kernels instead of the pipeline */
+    int pipe_wide = -1, pipe_nf = -1;                 /* pipeline kernel: geometry, FIR waves per workgroup */
+    int pipe_v = -1, pipe_g = -1;                     /* 1: rx_fused_pipe_kernel, 2: rx_pipe2_kernel; frames per workgroup of the latter */
+    int pipe_variant = -1;                            /* pipeline kernel: layout bits (kernels.h, FusedArgs::dbg) */
+    int hist_generic = -1;                            /* 1: the generic timing scan instead of the CYCLES = 8 one */
+};
+
+static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
+    {"QPSK_FUSED_G", &Tuning::fused_g},       {"QPSK_FUSED_S", &Tuning::fused_s},     {"QPSK_FUSED_LDS", &Tuning::fused_lds},
+    {"QPSK_FUSED_GENERIC", &Tuning::generic}, {"QPSK_PIPE_WIDE", &Tuning::pipe_wide}, {"QPSK_PIPE_NF", &Tuning::pipe_nf},
+    {"QPSK_PIPE_DBG", &Tuning::pipe_variant}, {"QPSK_HIST_GENERIC", &Tuning::hist_generic},
+    {"QPSK_PIPE_V", &Tuning::pipe_v},         {"QPSK_PIPE_G", &Tuning::pipe_g},
+};
+
+/* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
+ * result-changing ablation bits (1 skip the filter arithmetic, 2 skip the recurrence) and the cycle accounting (32)
+ * exist only in the measurement build (make profile, -DQPSK_PIPE_PROFILE) */
+#ifdef QPSK_PIPE_PROFILE
+static const int PIPE_VARIANT_MASK = ~0;
+#else
+static const int PIPE_VARIANT_MASK = 4 | 8 | 64 | 128;
+#endif
+
 struct qpsk_ctx {
     int device = 0;
+    Tuning tune;
     int ncu = 256;                /* compute units of the device (256 on MI355X) */
     hipStream_t stream = nullptr; /* caller's stream; nullptr = default stream */
     qpsk_params prm{};
@@ -63,7 +95,12 @@ struct qpsk_ctx {
     float min_freq = 0.f, max_freq = 0.f;
     float *d_taps = nullptr;     /* 128 floats */
     float *d_gains = nullptr;    /* MAX_BW x (alpha, beta) */
-    int *d_status = nullptr;     /* set by a kernel whose internal pipeline gave up (bounded spins) */
+    /* Status word, in pinned host memory that the device can write: a kernel stores a nonzero STATUS_* there when
+     * its results are invalid (its in-LDS pipeline exhausted the bounded spins; a loop phase beyond the bounded
+     * 2 pi wrap).  The host looks at it after EVERY synchronisation the library performs (check_status), so no
+     * entry point that hands results to the caller can return QPSK_OK over invalid ones. */
+    int *h_status = nullptr;     /* host view */
+    int *d_status = nullptr;     /* device view of the same word */
     std::vector<float> h_gains;
     DevBuf index, filtered, mixed, keystream;
     int keystream_len = 0;
@@ -95,6 +132,19 @@ static int ensure(qpsk_ctx *c, DevBuf &b, size_t bytes)
         return fail(QPSK_ERR_ALLOC, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
     }
     b.cap = bytes;
+    return QPSK_OK;
+}
+
+/* after a synchronisation of the context's stream: did a kernel of the calls just completed flag its results? */
+static int check_status(qpsk_ctx *c)
+{
+    const int st = __atomic_exchange_n(c->h_status, 0, __ATOMIC_ACQ_REL);
+    if (st == STATUS_PIPE_TIMEOUT)
+        return fail(QPSK_ERR_HIP, "pipeline kernel: producer/consumer wait timed out; results of the calls since the last synchronisation are invalid");
+    if (st == STATUS_PHASE_RANGE)
+        return fail(QPSK_ERR_RANGE, "Costas loop phase beyond the bounded 2 pi wrap (input amplitude far outside the modem's range; "
+                                    "the reference's phase_wrap() would spin or hang, costas_loop.c:61-67); results of the calls since the last synchronisation are invalid");
+    if (st != 0) return fail(QPSK_ERR_HIP, "kernel status %d", st);
     return QPSK_OK;
 }
 
@@ -182,6 +232,10 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
     KERNEL_TRY(prepare_pipe_kernel());
     qpsk_ctx *c = new qpsk_ctx();
     c->device = device;
+    for (const auto &k : TUNING_KEYS) {   /* the only place the environment is read */
+        const char *v = getenv(k.name);
+        if (v && *v) c->tune.*(k.field) = atoi(v);
+    }
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0)
@@ -198,11 +252,12 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
     c->max_freq = p->max_freq;
     if (hipMalloc((void **)&c->d_taps, 128 * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&c->d_gains, MAX_BW * 2 * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&c->d_status, sizeof(int)) != hipSuccess ||
-        hipMemset(c->d_status, 0, sizeof(int)) != hipSuccess) {
+        hipHostMalloc((void **)&c->h_status, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->d_status, c->h_status, 0) != hipSuccess) {
         qpsk_ctx_destroy(c);
         return fail(QPSK_ERR_ALLOC, "hipMalloc of configuration buffers failed");
     }
+    *c->h_status = 0;
     int rc = upload_config(c);
     if (rc != QPSK_OK) { qpsk_ctx_destroy(c); return rc; }
     *out = c;
@@ -232,7 +287,7 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
     hipStreamSynchronize(c->stream);
     hipFree(c->d_taps);
     hipFree(c->d_gains);
-    hipFree(c->d_status);
+    if (c->h_status) hipHostFree(c->h_status);
     hipFree(c->index.p);
     hipFree(c->filtered.p);
     hipFree(c->mixed.p);
@@ -248,14 +303,7 @@ int qpsk_ctx_sync(qpsk_ctx *c)
     if (!c) return fail(QPSK_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    /* a kernel whose in-LDS producer/consumer pipeline exhausted its bounded spins reports it here */
-    int st = 0;
-    HIP_TRY(hipMemcpy(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
-    if (st != 0) {
-        HIP_TRY(hipMemset(c->d_status, 0, sizeof(int)));
-        return fail(QPSK_ERR_HIP, "rx_fused_pipe_kernel: pipeline wait timed out (status %d); results of the last calls are invalid", st);
-    }
-    return QPSK_OK;
+    return check_status(c);
 }
 
 int qpsk_ctx_set_stream(qpsk_ctx *c, void *stream)
@@ -265,6 +313,17 @@ int qpsk_ctx_set_stream(qpsk_ctx *c, void *stream)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = (hipStream_t)stream;
     return QPSK_OK;
+}
+
+int qpsk_ctx_set_tuning(qpsk_ctx *c, const char *name, int value)
+{
+    if (!c || !name) return fail(QPSK_ERR_ARG, "null argument");
+    for (const auto &k : TUNING_KEYS)
+        if (!strcmp(k.name, name)) {
+            c->tune.*(k.field) = value < 0 ? -1 : value;
+            return QPSK_OK;
+        }
+    return fail(QPSK_ERR_ARG, "qpsk_ctx_set_tuning: unknown name '%s'", name);
 }
 
 int qpsk_ctx_cycles(const qpsk_ctx *c) { return c ? c->cycles : 0; }
@@ -302,11 +361,7 @@ int qpsk_ctx_set_loop(qpsk_ctx *c, float alpha, float beta, float min_freq, floa
 }
 
 /* ---------------------------------------------------------------- tiling */
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
+static int tuned(int v, int dflt) { return v >= 0 ? v : dflt; }
 
 /* frames per workgroup G and symbols per chunk S of rx_fused_kernel */
 static void pick_tiling(const qpsk_ctx *c, int nframes, int nbw, int *G, int *S)
@@ -315,12 +370,13 @@ static void pick_tiling(const qpsk_ctx *c, int nframes, int nbw, int *G, int *S)
     if (g < 1) g = 1;
     if (g > 64 / nbw) g = 64 / nbw;
     if (g < 1) g = 1;
-    g = env_int("QPSK_FUSED_G", g);
+    g = tuned(c->tune.fused_g, g);
+    if (g < 1) g = 1;
     if (g * nbw > 64) g = 64 / nbw;
-    int s = env_int("QPSK_FUSED_S", 64);
+    int s = tuned(c->tune.fused_s, 64);
     s &= ~7;
     if (s < 8) s = 8;
-    const size_t budget = (size_t)env_int("QPSK_FUSED_LDS", 64 * 1024);
+    const size_t budget = (size_t)tuned(c->tune.fused_lds, 64 * 1024);
     while (s > 8 && fused_lds_bytes(g, s, c->cycles, nbw) > budget) s -= 8;
     while (g > 1 && fused_lds_bytes(g, s, c->cycles, nbw) > (size_t)MAX_LDS_BYTES) g--;
     *G = g;
@@ -381,7 +437,7 @@ static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int
         if (rc) return rc;
         KERNEL_TRY(launch_rrc_fir(d_in, nullptr, (float *)c->filtered.p, c->d_taps, nframes, c->prm.frame_size, c->stream));
         KERNEL_TRY(launch_timing_hist((const float *)c->filtered.p, nframes, c->prm.frame_size, c->cycles,
-                                      (int32_t *)c->index.p, nullptr, c->stream));
+                                      (int32_t *)c->index.p, nullptr, tuned(c->tune.hist_generic, 0) != 0, c->stream));
         *d_index_out = (const int32_t *)c->index.p;
         return QPSK_OK;
     }
@@ -411,7 +467,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
     pick_tiling(c, nframes, nbw, &a.G, &a.S);
     a.index = idx;
     a.fixed_index = c->prm.fixed_index;
-    a.dbg = env_int("QPSK_PIPE_DBG", 0);
+    a.dbg = tuned(c->tune.pipe_variant, 0) & PIPE_VARIANT_MASK;
     a.taps = c->d_taps;
     a.gains = c->d_gains;
     a.nbw = nbw;
@@ -423,12 +479,30 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
     a.phase = d_phase;
     a.costas = reinterpret_cast<float2 *>(d_costas);
     a.hz = d_hz;
+    a.status = c->d_status;
     /* the pipeline kernel (rx_fused.hip) is built for CYCLES = 8, 16-byte aligned frames and an index
      * below CYCLES; everything else takes the generic chunked kernel (kernels.hip) */
     const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 &&
                          ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames(1, false) <= 64 &&
-                         !env_int("QPSK_FUSED_GENERIC", 0);
-    if (pipe_ok) {
+                         tuned(c->tune.generic, 0) == 0;
+    const int pipe_v = tuned(c->tune.pipe_v, 1);   /* rx_pipe2_kernel stays opt-in until it beats the 16-frame workgroups */
+    if (pipe_ok && pipe_v == 2) {
+        /* rx_pipe2_kernel: up to 32 frames per workgroup, one workgroup per CU when the batch allows it */
+        int G = (nframes + c->ncu - 1) / c->ncu;
+        if (G > pipe2_max_frames()) G = pipe2_max_frames();
+        G = tuned(c->tune.pipe_g, G);
+        if (G > pipe2_max_frames()) G = pipe2_max_frames();
+        if (G * nbw > 64) G = 64 / nbw;
+        if (G < 1) G = 1;
+        const int NU = (G + 1) / 2;
+        int nfir = NU < pipe2_max_fir() ? NU : pipe2_max_fir();
+        nfir = tuned(c->tune.pipe_nf, nfir);
+        if (nfir > pipe2_max_fir()) nfir = pipe2_max_fir();
+        if (nfir < 1) nfir = 1;
+        while (nfir < pipe2_max_fir() && nfir * pipe2_max_units_per_wave() < NU) nfir++;
+        while (G > 1 && pipe2_lds_bytes(G, nfir, nbw) > (size_t)MAX_LDS_BYTES) G--;   /* many loops per frame: the record rings grow */
+        KERNEL_TRY(launch_rx_pipe2(a, G, nfir, c->d_status, c->stream));
+    } else if (pipe_ok) {
         /* geometry: the narrow workgroups (16 frames, the serial wave alone on its SIMD) for every batch size; a
          * batch above 16 frames per CU runs them in rounds.  The wide ones (32 frames, FIR waves beside the serial
          * wave) were the faster choice for such batches while the serial wave wrote 16-byte records every step
@@ -437,14 +511,14 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
         auto fits = [&](int nf_, bool wide_) {   /* one lane of the serial wave per (frame, loop); rings grow with the loops */
             return pipe_frames(nf_, wide_) * nbw <= 64 && pipe_lds_bytes(nf_, nbw, wide_) <= (size_t)MAX_LDS_BYTES;
         };
-        const bool wide = env_int("QPSK_PIPE_WIDE", 0) != 0 && fits(1, true);
+        const bool wide = tuned(c->tune.pipe_wide, 0) != 0 && fits(1, true);
         const int full = pipe_max_nf(wide);
         int nf = full;
         if (!wide) {   /* just enough FIR waves to give every CU one workgroup */
             nf = 1;
             while (nf < full && (long long)c->ncu * pipe_frames(nf, false) < nframes) nf++;
         }
-        nf = env_int("QPSK_PIPE_NF", nf);
+        nf = tuned(c->tune.pipe_nf, nf);
         if (nf < 1) nf = 1;
         if (nf > full) nf = full;
         while (nf > 1 && !fits(nf, wide)) nf--;
@@ -499,9 +573,9 @@ static int costas_over_symbols(qpsk_ctx *c, float *d_symbols, int nframes, int n
                                uint8_t *d_sym, float *d_costas, const float *refill = nullptr,
                                const int32_t *refill_index = nullptr)
 {
-    if (env_int("QPSK_FUSED_GENERIC", 0)) {
+    if (tuned(c->tune.generic, 0)) {
         KERNEL_TRY(launch_costas(d_symbols, nframes, nsym, dstride, 1, c->d_gains, c->min_freq, c->max_freq, d_state, d_state,
-                                 d_sym, d_costas, c->stream));
+                                 d_sym, d_costas, c->d_status, c->stream));
         if (refill) {
             if (dstride != nsym) return fail(QPSK_ERR_ARG, "internal: refill needs packed rows");
             KERNEL_TRY(launch_decimate(refill, refill_index, d_symbols, nframes, nsym * c->cycles, c->cycles, nsym, c->stream));
@@ -527,7 +601,8 @@ static int costas_over_symbols(qpsk_ctx *c, float *d_symbols, int nframes, int n
     a.costas = reinterpret_cast<float2 *>(d_costas);
     a.dsrc = reinterpret_cast<const float2 *>(d_symbols);
     a.dstride = dstride;
-    a.dbg = env_int("QPSK_PIPE_DBG", 0);
+    a.status = c->d_status;
+    a.dbg = tuned(c->tune.pipe_variant, 0) & PIPE_VARIANT_MASK;
     int nf = (nframes + c->ncu * pipe_frames(1, false) - 1) / (c->ncu * pipe_frames(1, false));
     if (nf < 1) nf = 1;
     if (nf > pipe_max_nf(false)) nf = pipe_max_nf(false);
@@ -560,7 +635,8 @@ int qpsk_timing_hist_batch(qpsk_ctx *c, const float *d_filtered, int nframes, in
     if (!c || !d_filtered || !d_index) return fail(QPSK_ERR_ARG, "qpsk_timing_hist_batch: null argument");
     if (nframes <= 0) return fail(QPSK_ERR_ARG, "nframes = %d", nframes);
     if (bind(c)) return QPSK_ERR_HIP;
-    KERNEL_TRY(launch_timing_hist(d_filtered, nframes, c->prm.frame_size, c->cycles, d_index, d_hist, c->stream));
+    KERNEL_TRY(launch_timing_hist(d_filtered, nframes, c->prm.frame_size, c->cycles, d_index, d_hist,
+                                  tuned(c->tune.hist_generic, 0) != 0, c->stream));
     return QPSK_OK;
 }
 
@@ -638,7 +714,7 @@ int qpsk_streams_get_loop_state(qpsk_ctx *c, float *h_state)
     if (bind(c)) return QPSK_ERR_HIP;
     HIP_TRY(hipMemcpyAsync(h_state, c->s_loop, sizeof(float) * 2 * (size_t)c->nstreams, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return QPSK_OK;
+    return check_status(c);
 }
 
 int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *d_freq, float *d_phase,
@@ -659,7 +735,7 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
     KERNEL_TRY(launch_delay_line(d_in, c->s_memory, n, L, c->stream));
     /* qpsk.c:127-180 */
     if (c->prm.timing_mode == QPSK_TIMING_HIST)
-        KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, nullptr, c->stream));
+        KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, nullptr, tuned(c->tune.hist_generic, 0) != 0, c->stream));
     else if (c->prm.timing_mode == QPSK_TIMING_FIXED)
         KERNEL_TRY(launch_fill_i32(idx, n, c->prm.fixed_index, c->stream));
     else if (int rf = fft_timing_indices(c, d_in, n, idx))   /* stateless: it looks at the raw block from sample 2 on */
@@ -811,7 +887,7 @@ int qpsk_dev_download(qpsk_ctx *c, void *h_dst, const void *d_src, size_t bytes)
     if (bind(c)) return QPSK_ERR_HIP;
     HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return QPSK_OK;
+    return check_status(c);   /* the bytes just handed over may come from a call whose kernel flagged its results */
 }
 
 /* test hook: order-independent hash of the device sin/cos over float bit patterns [first, first+count) in both signs */

@@ -12,6 +12,9 @@ constexpr int LOOKBACK = 128;  /* >= 126 samples of FIR history, kept 16-byte fr
 constexpr int LOOKAHEAD = 8;   /* the decimation offset can reach 7 (qpsk.c:173-180) */
 constexpr int MAX_LDS_BYTES = 160 * 1024;
 constexpr int MAX_INDEX = 7;
+/* values a kernel stores in the context's status word (FusedArgs::status; api.cpp check_status) */
+constexpr int STATUS_PIPE_TIMEOUT = 1;   /* the in-LDS producer/consumer pipeline exhausted its bounded spins */
+constexpr int STATUS_PHASE_RANGE = 2;    /* a loop phase beyond the bounded 2 pi wrap (qpsk_device.h, phase_wrap) */
 
 struct FusedArgs {
     const float2 *x;        /* [nframes][frame_size] */
@@ -22,9 +25,11 @@ struct FusedArgs {
                                per lane; 2 = every FIR wave 2 frames with 2 symbols per lane (see the kernel) */
     const int32_t *index;   /* [nframes] or NULL -> fixed_index */
     int fixed_index;
-    int dbg;                /* measurement only (QPSK_PIPE_DBG): 1 skip FIR arithmetic, 2 skip the Costas recurrence,
-                               4 no spare waves, 8 C++ Costas step, 32 print the cycle accounting of workgroup 0's FIR
-                               waves (profile build), 128 one lane mapping for all FIR waves (the plain layout) */
+    int dbg;                /* layout variants of the pipeline kernel, all bit-exact (qpsk_ctx_set_tuning "QPSK_PIPE_DBG"):
+                               4 no spare waves, 8 C++ Costas step, 128 one lane mapping for all FIR waves (the plain
+                               layout).  Measurement build only (-DQPSK_PIPE_PROFILE; masked off by api.cpp otherwise):
+                               1 skip FIR arithmetic, 2 skip the Costas recurrence (both change the result), 32 print the
+                               cycle accounting of workgroup 0's FIR waves */
     const float2 *dsrc;     /* costas_pipe_kernel only: decimated symbols, rows dstride symbols apart */
     int dstride;
     /* costas_pipe_kernel, streaming mode (qpsk.c:186-191): once symbol i of a row has been taken, its slot is
@@ -43,6 +48,8 @@ struct FusedArgs {
     float *freq, *phase;    /* [nframes][nbw] or NULL */
     float2 *costas;         /* [nframes][nbw][nsym] or NULL */
     float *hz;              /* [nframes][nbw] or NULL */
+    int *status;            /* the context's status word (pinned host memory): a kernel stores STATUS_* there when a
+                               call's results are invalid (pipeline timeout, phase beyond the bounded 2 pi wrap) */
 };
 
 size_t fused_lds_bytes(int G, int S, int cycles, int nbw);
@@ -56,13 +63,19 @@ int pipe_max_nf(bool wide);            /* FIR waves per workgroup: narrow 4 (16 
 int prepare_pipe_kernel(void);
 int launch_rx_fused_pipe(const FusedArgs &a, int NF, bool wide, int *status, hipStream_t s);
 int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s);
+/* rx_fused.hip: the pipeline kernel for up to 32 frames per workgroup (two-frame units, per-wave windows) */
+size_t pipe2_lds_bytes(int G, int nfir, int nbw);
+int pipe2_max_fir(void);
+int pipe2_max_frames(void);
+int pipe2_max_units_per_wave(void);
+int launch_rx_pipe2(const FusedArgs &a, int G, int nfir, int *status, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s);
 int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s);
 int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, int32_t *hist,
-                       hipStream_t s);
+                       bool generic, hipStream_t s);   /* generic: always the any-CYCLES scan (test knob) */
 int launch_costas(const float *d, int nframes, int nsym, int dstride, int nbw, const float *gains, float min_freq,
-                  float max_freq, const float *state_in, float *state_out, uint8_t *sym, float *costas,
+                  float max_freq, const float *state_in, float *state_out, uint8_t *sym, float *costas, int *status,
                   hipStream_t s);
 int launch_decimate(const float *filtered, const int32_t *index, float *dec, int nstreams, int frame_size,
                     int cycles, int nsym, hipStream_t s);

@@ -67,6 +67,7 @@ rx_fused_kernel(FusedArgs a)
     const int lane_g = tid / nbw, lane_b = tid % nbw;
     const bool costas_lane = tid < gcount * nbw && tid < 64;
     Loop st = {0.0f, 0.0f};
+    bool over = false;   /* a phase beyond the bounded 2 pi wrap (qpsk_device.h) */
     LoopGains lg = {0.0f, 0.0f, a.min_freq, a.max_freq};
     if (costas_lane) {
         lg.alpha = a.gains[2 * lane_b];
@@ -116,7 +117,7 @@ rx_fused_kernel(FusedArgs a)
             const int cnt = min(S, N - sym0);
             const float2 *dl = ds + (size_t)lane_g * S;
             for (int j = 0; j < cnt; j++) {
-                const float2 z = (c == 0 && j == 0) ? costas_step<true>(st, lg, dl[j]) : costas_step<false>(st, lg, dl[j]);
+                const float2 z = (c == 0 && j == 0) ? costas_step<true>(st, lg, dl[j], over) : costas_step<false>(st, lg, dl[j], over);
                 ss[(size_t)tid * S + j] = (uint8_t)slicer(z);
                 if (a.costas)
                     zs[(size_t)tid * S + j] = z;
@@ -149,6 +150,7 @@ rx_fused_kernel(FusedArgs a)
             a.state_out[2 * o] = st.phase;
             a.state_out[2 * o + 1] = st.freq;
         }
+        if (over && a.status) __hip_atomic_store(a.status, STATUS_PHASE_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -497,7 +499,7 @@ timing_hist8_kernel(const float *__restrict__ y, int nframes, int frame_size, in
 __global__ void __launch_bounds__(64)
 costas_kernel(const float2 *__restrict__ d, int nframes, int nsym, int dstride, int nbw, const float *__restrict__ gains,
               float min_freq, float max_freq, const float *state_in, float *state_out, uint8_t *sym,
-              float2 *costas)
+              float2 *costas, int *status)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= nframes * nbw) return;
@@ -505,13 +507,15 @@ costas_kernel(const float2 *__restrict__ d, int nframes, int nsym, int dstride, 
     Loop st = {0.0f, 0.0f};
     if (state_in) { st.phase = state_in[2 * t]; st.freq = state_in[2 * t + 1]; }
     const LoopGains lg = {gains[2 * b], gains[2 * b + 1], min_freq, max_freq};
+    bool over = false;
     const float2 *p = d + (size_t)f * dstride;
     for (int i = 0; i < nsym; i++) {
-        const float2 z = i == 0 ? costas_step<true>(st, lg, p[i]) : costas_step<false>(st, lg, p[i]);
+        const float2 z = i == 0 ? costas_step<true>(st, lg, p[i], over) : costas_step<false>(st, lg, p[i], over);
         if (sym) sym[(size_t)t * nsym + i] = (uint8_t)slicer(z);
         if (costas) costas[(size_t)t * nsym + i] = z;
     }
     if (state_out) { state_out[2 * t] = st.phase; state_out[2 * t + 1] = st.freq; }
+    if (over && status) __hip_atomic_store(status, STATUS_PHASE_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* ========================================================================
@@ -739,9 +743,8 @@ int launch_delay_line(const float *x, float *memory, int nframes, int length, hi
 }
 
 int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, int32_t *hist,
-                       hipStream_t s)
+                       bool generic, hipStream_t s)
 {
-    const bool generic = getenv("QPSK_HIST_GENERIC") != nullptr;   /* test knob: always the generic scan */
     if (cycles == 8 && frame_size % TH8_TILE == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && !generic) {
         hipLaunchKernelGGL(timing_hist8_kernel, dim3((nframes + TH8_FRAMES - 1) / TH8_FRAMES), dim3(64), 0, s, y,
                            nframes, frame_size, index, hist);
@@ -755,13 +758,13 @@ int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, 
 }
 
 int launch_costas(const float *d, int nframes, int nsym, int dstride, int nbw, const float *gains, float min_freq,
-                  float max_freq, const float *state_in, float *state_out, uint8_t *sym, float *costas,
+                  float max_freq, const float *state_in, float *state_out, uint8_t *sym, float *costas, int *status,
                   hipStream_t s)
 {
     const int threads = nframes * nbw;
     hipLaunchKernelGGL(costas_kernel, dim3((threads + 63) / 64), dim3(64), 0, s,
                        reinterpret_cast<const float2 *>(d), nframes, nsym, dstride, nbw, gains, min_freq, max_freq,
-                       state_in, state_out, sym, reinterpret_cast<float2 *>(costas));
+                       state_in, state_out, sym, reinterpret_cast<float2 *>(costas), status);
     LAUNCH_CHECK();
     return 0;
 }

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sincos_f32.h"
+#include "kernels.h"
 
 namespace qpsk {
 
@@ -62,13 +63,26 @@ struct LoopGains {
     float alpha, beta, min_freq, max_freq; /* costas_loop.c:16-23 */
 };
 
-/* costas_loop.c:61-67: float phase against the DOUBLE 2*pi */
-__device__ __forceinline__ float phase_wrap(float p)
+/* costas_loop.c:61-67: float phase against the DOUBLE 2*pi.
+ * The reference's loops are unbounded: a phase of 2^27 or more never moves ((float)((double)p - TAU) == p) and the
+ * CPU process hangs; below that it takes |p| / TAU iterations.  A GPU wave must not spin like that, so the loops
+ * stop after WRAP_LIMIT iterations (|phase| > ~25,000 rad: inputs some 10^5 times the modem's working amplitude),
+ * `over` is raised -- the kernel reports it through its status word and the call fails with QPSK_ERR_RANGE -- and
+ * the phase restarts from 0 so that the rest of the frame runs at its normal cost.  Every phase the reference
+ * wraps in at most WRAP_LIMIT steps is wrapped exactly as it does. */
+constexpr int WRAP_LIMIT = 4096;
+
+__device__ __forceinline__ float phase_wrap(float p, bool &over)
 {
-    while (p >= TAU_F)
+    int n = 0;
+    while (p >= TAU_F) {
         p = (float)((double)p - TAU);
-    while (p <= -TAU_F)
+        if (++n > WRAP_LIMIT) { over = true; return 0.0f; }
+    }
+    while (p <= -TAU_F) {
         p = (float)((double)p + TAU);
+        if (++n > WRAP_LIMIT) { over = true; return 0.0f; }
+    }
     return p;
 }
 
@@ -85,7 +99,7 @@ __device__ __forceinline__ int slicer(float2 z)
  * identical for every other argument and a -0 phase can only be LOADED, never produced by the loop
  * (x + y is -0 only if both are), so callers run their first step with EXACT_ZERO = true. */
 template <bool EXACT_ZERO = false>
-__device__ __forceinline__ float2 costas_step(Loop &st, const LoopGains &g, float2 d)
+__device__ __forceinline__ float2 costas_step(Loop &st, const LoopGains &g, float2 d, bool &over)
 {
     const SinCos w = EXACT_ZERO ? sincos_f32(st.phase) : sincos_f32_costas(st.phase);
     /* d * (cos - j sin)  (qpsk.c:197, qpsk.h:36) */
@@ -96,7 +110,7 @@ __device__ __forceinline__ float2 costas_step(Loop &st, const LoopGains &g, floa
     const float e = (z.x > 0.0f ? z.y : -z.y) - (z.y > 0.0f ? z.x : -z.x);
     /* costas_loop.c:56-59 */
     st.freq = st.freq + g.beta * e;
-    st.phase = phase_wrap(st.phase + st.freq + g.alpha * e);
+    st.phase = phase_wrap(st.phase + st.freq + g.alpha * e, over);
     /* costas_loop.c:69-74 */
     if (st.freq > g.max_freq)
         st.freq = g.max_freq;
@@ -114,7 +128,7 @@ __device__ __forceinline__ float2 costas_step(Loop &st, const LoopGains &g, floa
  */
 template <bool FAST_CLAMP>
 __device__ __forceinline__ float2 costas_step_lean(float &phase, float &freq, float alpha, float beta,
-                                                   float min_freq, float max_freq, float2 d)
+                                                   float min_freq, float max_freq, float2 d, bool &over)
 {
     const SinCos w = sincos_f32_costas(phase);
     float2 z;
@@ -124,7 +138,7 @@ __device__ __forceinline__ float2 costas_step_lean(float &phase, float &freq, fl
     float f = freq + beta * e;
     float p = phase + f + alpha * e;
     if (__builtin_expect(__any(fabsf(p) >= TAU_F), 0))
-        p = phase_wrap(p);
+        p = phase_wrap(p, over);
     if (FAST_CLAMP)
         f = __builtin_amdgcn_fmed3f(f, min_freq, max_freq);
     else
@@ -188,7 +202,7 @@ __device__ __forceinline__ float2 derotate(float phase, float2 d)
 
 template <bool FAST_CLAMP>
 __device__ __forceinline__ void costas_step_t(float &phase, float &freq, float alpha, float beta, float min_freq,
-                                              float max_freq, float2 d, float &tx, float &ty, unsigned &q)
+                                              float max_freq, float2 d, float &tx, float &ty, unsigned &q, bool &over)
 {
     const SinCosRaw w = sincos_raw_horner(phase);
     tx = d.x * w.c + d.y * w.s;
@@ -206,7 +220,7 @@ __device__ __forceinline__ void costas_step_t(float &phase, float &freq, float a
             f = freq + beta * e;
             p = phase + f + alpha * e;
         }
-        p = phase_wrap(p);
+        p = phase_wrap(p, over);
     }
     if (FAST_CLAMP)
         f = __builtin_amdgcn_fmed3f(f, min_freq, max_freq);

@@ -53,8 +53,17 @@ namespace pipe {
 
 constexpr int C = 8;            /* CYCLES this instantiation is built for */
 constexpr int DR = 2;            /* depth of the symbol rings in chunks */
-constexpr int MAX_WAVES = 8;     /* FIR waves of the widest geometry */
+constexpr int MAX_WAVES = 16;    /* ready[] counters: FIR waves of the widest geometry / two-frame units of rx_pipe2_kernel */
 constexpr int SPIN_LIMIT = 1 << 24;
+
+/* Result-changing ablation knobs (FusedArgs::dbg bit 0: skip the filter arithmetic, bit 1: skip the recurrence) exist
+ * only in the measurement build (make -C qpsk_amd/csrc profile); the product library computes the reference's
+ * result whatever the environment says. */
+#ifdef QPSK_PIPE_PROFILE
+#define QPSK_ABLATE(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define QPSK_ABLATE(a, bit) false
+#endif
 
 /*
  * Geometry of a workgroup.  The LDS (window + rings per frame) decides how many frames it holds:
@@ -128,6 +137,12 @@ __device__ __forceinline__ void st_release(int *p, int v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+/* the context's status word lives in pinned host memory (api.cpp): the host reads it after any synchronisation */
+__device__ __forceinline__ void report_status(int *status, int what)
+{
+    __hip_atomic_store(status, what, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /* bounded wait until *p >= target; false if the workgroup gave up */
 __device__ __forceinline__ bool wait_ge(int *p, int target, int *abort_flag)
 {
@@ -180,19 +195,37 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
     /* one median-of-3 instead of two compare/select pairs when the clamp is the usual min < 0 < max */
     const bool fast_clamp = a.min_freq < 0.0f && a.max_freq > 0.0f;
     float ph = st.phase, fr = st.freq;
+    bool over = false;   /* a phase beyond the bounded 2 pi wrap (qpsk_device.h, phase_wrap) */
     const float al = lg.alpha, be = lg.beta, fmin_ = a.min_freq, fmax_ = a.max_freq;
     bool ok = true;
+#ifdef QPSK_PIPE_PROFILE
+    const bool cprof = (a.dbg & 32) && blockIdx.x == 0;
+    unsigned long long cw = 0, cs = 0, ct = 0;
+    auto ctick = [&](unsigned long long &acc) {
+        if (cprof) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            acc += t - ct;
+            ct = t;
+        }
+    };
+    unsigned long long dummy = 0;
+    ctick(dummy);
+#endif
     for (int c = 0; c < nchunks && ok; c++) {
         ok = wait_ge(&sm->ready[gw], c + 1, &sm->abort_flag);
         if (!__all(ok)) { ok = false; break; }
+#ifdef QPSK_PIPE_PROFILE
+        ctick(cw);
+#endif
         const int slot = (c % DR) * S;
         const int cnt = min(S, N - c * S);
-        if (active && !(a.dbg & 2)) { /* ablation knob (QPSK_PIPE_DBG bit 1): skip the recurrence */
+        if (active && !QPSK_ABLATE(a, 2)) { /* measurement build only: skip the recurrence */
             int j = 0;
             if (c == 0) { /* a loaded phase may be -0: first step with the form that is exact there too */
                 Loop s0 = {ph, fr};
                 zl[slot] = ph;
-                costas_step<true>(s0, lg, dl[slot]);
+                costas_step<true>(s0, lg, dl[slot], over);
                 ph = s0.phase; fr = s0.freq;
                 j = 1;
                 /* the stream below starts on a symbol number that is a multiple of 4 (16-byte aligned reads of
@@ -200,8 +233,8 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
                 for (; j < min(4, cnt); j++) {
                     float tx, ty; unsigned qq;
                     zl[slot + j] = ph;
-                    if (fast_clamp) costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
-                    else costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
+                    if (fast_clamp) costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq, over);
+                    else costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq, over);
                 }
             }
             /* the wave only advances the loop and leaves each step's starting phase; de-rotation to z (sin/cos
@@ -226,7 +259,7 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
                         for (int i = 0; i < AG; i++, j++) {
                             float tx, ty; unsigned qq;
                             zl[slot + j] = ph;
-                            costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq);
+                            costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[slot + j], tx, ty, qq, over);
                         }
                     }
                 }
@@ -238,7 +271,7 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
                     const float2 dnext = dl[slot + j + 1];
                     float tx, ty; unsigned qq;
                     zl[slot + j] = ph;
-                    costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
+                    costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq, over);
                     dcur = dnext;
                 }
             } else {
@@ -247,13 +280,20 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
                     const float2 dnext = dl[slot + j + 1];
                     float tx, ty; unsigned qq;
                     zl[slot + j] = ph;
-                    costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq);
+                    costas_step_t<false>(ph, fr, al, be, fmin_, fmax_, dcur, tx, ty, qq, over);
                     dcur = dnext;
                 }
             }
         }
         if (lane == 0) st_release(&sm->consumed, c + 1);
+#ifdef QPSK_PIPE_PROFILE
+        ctick(cs);
+#endif
     }
+#ifdef QPSK_PIPE_PROFILE
+    if (cprof && lane == 0)
+        printf("serial wave: %d chunks; cycles per chunk: wait for the FIR waves %llu, steps %llu\n", nchunks, cw / nchunks, cs / nchunks);
+#endif
     st.phase = ph; st.freq = fr;
     if (active && ok) {
         const size_t o = (size_t)(f0 + g) * nbw + b;
@@ -262,7 +302,8 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
         if (a.hz) a.hz[o] = (float)((double)st.freq * a.rs / TAU); /* qpsk.c:217 */
         if (a.state_out) { a.state_out[2 * o] = st.phase; a.state_out[2 * o + 1] = st.freq; }
     }
-    if (!ok && lane == 0) atomicExch(status, 1);
+    if (!ok && lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
+    if (over) report_status(status, STATUS_PHASE_RANGE);
 }
 
 /*
@@ -409,7 +450,7 @@ costas_pipe_kernel(FusedArgs a, int *status)
             for (; flushed < nchunks; flushed++)
                 if (fvalid) flush_records<GM>(a, zring, dring, g, frame, q, flushed);
     }
-    if (!ok && lane == 0) atomicExch(status, 1);
+    if (!ok && lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
 }
 
 template <class GM>
@@ -618,14 +659,14 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         const float2 *rd = cx.rd;
         float2 acc[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = (a.dbg & 1) ? make_float2(0.7f, 0.3f) : make_float2(0.0f, 0.0f);
+        for (int r = 0; r < R; r++) acc[r] = QPSK_ABLATE(a, 1) ? make_float2(0.7f, 0.3f) : make_float2(0.0f, 0.0f);
         /* t = C*tb + u: symbol r needs tap group tb - r (taps C*(tb-r) .. +C-1), so each group of C taps is
          * live for R consecutive blocks */
         static_assert(C == 8 && (R == 4 || R == 2), "the step below is written for C = 8 and R = 2 or 4");
         if constexpr (!GM::PINNED) {
             /* the compiler's own schedule of the same sum (a Geom with PINNED = false; no longer instantiated):
              * config 2 ran 0.2148 ms with it against 0.2088 ms with the pinned order below [measured, same process] */
-            if (!(a.dbg & 1)) {
+            if (!QPSK_ABLATE(a, 1)) {
                 float tgc[R][C];
 #pragma unroll
                 for (int tb = 0; tb * C < TSTEPS; tb++) {
@@ -648,7 +689,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                     }
                 }
             }
-        } else if (!(a.dbg & 1)) { /* ablation knob (QPSK_PIPE_DBG bit 0): skip the filter arithmetic, keep the traffic */
+        } else if (!QPSK_ABLATE(a, 1)) { /* measurement build only: skip the filter arithmetic, keep the traffic */
             /* Software pipeline, one block of C window positions deep: the LDS reads of block tb+1 (window values
              * and tap group) are issued before the multiply-adds of block tb.  Groups rotate through R + 1 slots so
              * that the group fetched a block early does not overwrite the one symbol R-1 still needs.
@@ -751,7 +792,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         if (ok)
             for (int c = max(0, nchunks - DR); c < nchunks; c++) flush_chunk(c);
     }
-    if (!ok && lane == 0) atomicExch(status, 1);
+    if (!ok && lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
 #ifdef QPSK_PIPE_PROFILE
     if (prof && lane == 0)
         printf("FIR wave %d (%d symbols per lane): %d chunks; cycles per chunk: wait for the loop %llu, flush %llu, history + window %llu, "
@@ -767,6 +808,324 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         }
     }
     fir_wave(WaveMap<GM::QL, GM::R>{});
+}
+
+
+/* ========================================================================
+ * rx_pipe2_kernel: the same pipeline laid out for up to 32 frames per workgroup (BASELINE config 4's per-GPU
+ * share: 8192 frames = 32 per CU), where the recurrence costs the serial wave no more than for 16 frames and the
+ * FILTER decides the time.  Measured on the layouts above: a FIR wave alone on its SIMD issues a
+ * packed instruction every 6.2 cycles (every LDS instruction costs it ~15), two on one SIMD 4.07 between them (the
+ * SIMD's rate); the serial wave loses half its speed as soon as anything shares its SIMD.  Hence:
+ *   wave 0            the serial wave, alone on its SIMD (hardware waves 4 and 8 retire at once);
+ *   hardware waves 1-3, 5-7, 9-11   up to nine FIR waves, two or three on each of the other SIMDs;
+ *   unit              2 frames x 64 symbols of one chunk, lane = (frame of 2) x (q of 32), 2 symbols per lane.
+ *                     FIR wave i owns units i, i + nfir (static), so SIMDs 1-3 carry 6, 5, 5 of a full
+ *                     workgroup's 16 units.
+ * What makes 32 frames fit the 160 KB: the window (hist + one chunk of samples, 5.4 KB per frame) belongs to the
+ * WAVE, not the frame -- a wave stages, filters and hands over one unit after the other in the same 10.9 KB -- and
+ * the 126 samples of history a frame carries from chunk to chunk stay in the owner's REGISTERS (they are the last
+ * 128-sample block it loaded: 4 VGPRs per frame), so there is no history copy through LDS and no window to zero.
+ * Rings, records, flush and the serial wave are those of rx_fused_pipe_kernel (costas_wave, flush_records).
+ * ======================================================================== */
+#ifndef QPSK_PIPE2_MAXFIR
+#define QPSK_PIPE2_MAXFIR 9  /* FIR waves per workgroup: 9 = three per SIMD (at most 168 VGPRs), 6 = two per SIMD */
+#endif
+#ifndef QPSK_PIPE2_DEPTH
+#define QPSK_PIPE2_DEPTH 2   /* blocks of 8 window positions fetched ahead of their use (measured: see DESIGN.md 4.1) */
+#endif
+namespace pipe2 {
+constexpr int QL = 32, R = 2, UF = 2;                    /* lanes per frame, symbols per lane, frames per unit */
+constexpr int S = GeomNarrow::S, CH = S * C;              /* 64 symbols = 512 samples per chunk per frame */
+constexpr int PAD = R * C;                                /* 16: position p lives at slot p + p/16, lanes 17 slots apart */
+constexpr int TSTEPS = NTAPS + C * (R - 1);               /* 135 window positions per lane per chunk */
+constexpr int NLD = CH / 128;                             /* 16-byte loads per frame per chunk */
+constexpr int BLK = 128 + 128 / PAD;                      /* slots per 128-sample block */
+constexpr int WS = 680;                                   /* slots per frame window: positions 0..637 -> slots 0..676 */
+constexpr int MAX_UNITS = 16, MAX_FIR = QPSK_PIPE2_MAXFIR, MAX_UW = (MAX_UNITS + MAX_FIR - 1) / MAX_FIR;   /* units per workgroup, FIR waves, units per FIR wave */
+constexpr int MAX_THREADS = 64 * (MAX_FIR + 1 + (MAX_FIR - 1) / 3);   /* 12 hardware waves */
+static_assert(S == QL * R && CH % 128 == 0 && (CH + HIST - 1) + (CH + HIST - 1) / PAD < WS &&
+              PAD * (QL - 1) + TSTEPS - 1 <= CH + HIST - 1 - (C - 1), "window geometry: every position a lane reads is written for every index < C");
+static_assert(MAX_UNITS <= MAX_WAVES, "one ready[] counter per unit");
+
+/* what a FIR wave keeps per unit (wave-uniform except where noted) */
+struct Unit {
+    int u;                    /* unit number in the workgroup = its ready[] counter; frames 2u, 2u + 1 */
+    bool fv[UF], all_valid;   /* frames inside the batch */
+    const float4 *src[UF];
+    int wr0[UF], wr1[UF];     /* per lane: window slots of the pair this lane loads from block 0 of a chunk */
+    float4 hist[UF];          /* per lane: the pair it loaded from the LAST block of the previous chunk */
+};
+} // namespace pipe2
+
+template <int NUW>
+__device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *mywin, float2 *dring, float *zring, int G,
+                                          int widx, int nfir, int f0, int lane, int nchunks, int *status)
+{
+    using namespace pipe2;
+    using GM = GeomNarrow;    /* ring geometry (S, DSTRIDE, ZSTRIDE) shared with costas_wave / flush_records */
+    constexpr int DSTRIDE = GM::DSTRIDE;
+    const int L = a.frame_size;
+    const int fl = lane / QL, q = lane % QL;
+    const float4 *taps4 = reinterpret_cast<const float4 *>(sm->taps);
+    const float2 *rd = mywin + fl * WS + (PAD + 1) * q;      /* FIR read base: position PAD*q -> slot (PAD+1)*q */
+
+    Unit un[NUW];
+#pragma unroll
+    for (int ui = 0; ui < NUW; ui++) {
+        Unit &U = un[ui];
+        U.u = widx + ui * nfir;
+        U.all_valid = UF * U.u + UF <= G && f0 + UF * U.u + UF <= a.nframes;
+#pragma unroll
+        for (int ff = 0; ff < UF; ff++) {
+            const int fr = f0 + UF * U.u + ff;
+            U.fv[ff] = UF * U.u + ff < G && fr < a.nframes;      /* an odd G leaves the last unit one frame */
+            const int ix = a.index ? (U.fv[ff] ? a.index[fr] : 0) : a.fixed_index;   /* decimation offset, < C */
+            const int p0 = 2 * lane + HIST - ix;                    /* window position of sample 2*lane of the chunk */
+            U.wr0[ff] = ff * WS + p0 + p0 / PAD;
+            U.wr1[ff] = ff * WS + (p0 + 1) + (p0 + 1) / PAD;
+            U.src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(U.fv[ff] ? fr : 0) * L);
+            U.hist[ff] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       /* a fresh delay line (qpsk.c:37) */
+        }
+    }
+
+    /* loads are UNCONDITIONAL (a per-load branch would make the compiler wait for each in turn): a chunk that lies
+     * inside every frame of the unit loads straight; the tail chunk clamps the address and zeroes what lies past the
+     * end.  L is even on this path (host-checked), so a 16-byte pair is either inside the frame or past it. */
+    auto prefetch = [&](const Unit &U, float4 (&pre)[UF][NLD], int c) {
+        if (U.all_valid && (c + 1) * CH <= L) {
+#pragma unroll
+            for (int ff = 0; ff < UF; ff++)
+#pragma unroll
+                for (int j = 0; j < NLD; j++)
+                    pre[ff][j] = U.src[ff][(c * CH + 128 * j + 2 * lane) >> 1];
+        } else {
+#pragma unroll
+            for (int ff = 0; ff < UF; ff++)
+#pragma unroll
+                for (int j = 0; j < NLD; j++) {
+                    const int s = c * CH + 128 * j + 2 * lane;
+                    const bool in = U.fv[ff] && s + 1 < L;
+                    float4 v = U.src[ff][in ? (s >> 1) : 0];
+                    if (!in) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    pre[ff][j] = v;
+                }
+        }
+    };
+
+#ifdef QPSK_PIPE_PROFILE
+    const bool prof = (a.dbg & 32) && blockIdx.x == 0;
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = 0;
+    auto tick = [&](int k) {
+        if (prof) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            if (k >= 0) tacc[k] += t - tlast;
+            tlast = t;
+        }
+    };
+#else
+    auto tick = [](int) {};
+#endif
+
+    /* one unit of one chunk: stage the window from registers, start the next loads, filter, flush what the loop has
+     * finished with, hand over */
+    auto run_unit = [&](Unit &U, float4 (&pre)[UF][NLD], int c, const Unit &next, bool has_next, int cnext) -> bool {
+        /* history (the previous chunk's last block, one block below block 0: the lanes whose pair lies before
+         * the first tap's reach are skipped), then this chunk's samples */
+#pragma unroll
+        for (int ff = 0; ff < UF; ff++) {
+            if (U.wr0[ff] - ff * WS - BLK >= 0) mywin[U.wr0[ff] - BLK] = make_float2(U.hist[ff].x, U.hist[ff].y);
+            if (U.wr1[ff] - ff * WS - BLK >= 0) mywin[U.wr1[ff] - BLK] = make_float2(U.hist[ff].z, U.hist[ff].w);
+#pragma unroll
+            for (int j = 0; j < NLD; j++) {
+                mywin[U.wr0[ff] + BLK * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
+                mywin[U.wr1[ff] + BLK * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
+            }
+            U.hist[ff] = pre[ff][NLD - 1];
+        }
+        if (has_next) prefetch(next, pre, cnext);
+        tick(2);
+
+        /* sliding-window FIR, the pinned two-symbol step of rx_fused_pipe_kernel: symbol r of this lane uses tap
+         * k = t - C*r at window position PAD*q + t; taps 0..126 in order into one accumulator per symbol */
+        v2f ac[R] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
+        if (!QPSK_ABLATE(a, 1)) {
+            /* Two symbols per lane leave a lone multiply/add pair per symbol and window position: too little
+             * independent work for a wave that waits 8 cycles on every dependent result.  So positions go in PAIRS:
+             * the four products of positions t, t+1 (two symbols each), then the four adds -- each accumulator still
+             * receives its taps in order 0..126 (rrc_fir.c:22-26), an add follows its product by 4 instructions and
+             * the previous add of its accumulator by 2.  Window values and tap groups are fetched from LDS DEPTH
+             * blocks of 8 positions ahead of their use. */
+            constexpr int NB = (TSTEPS + C - 1) / C, DEPTH = QPSK_PIPE2_DEPTH, NW = DEPTH + 1, NG = R + DEPTH;
+            float tg[NG][C];
+            float2 wv[NW][C];
+            auto fetch_block = [&](int tb) {
+                if (tb * C < NTAPS) {
+                    const float4 ta = taps4[2 * tb], tb4 = taps4[2 * tb + 1];
+                    float *g_ = tg[tb % NG];
+                    g_[0] = ta.x; g_[1] = ta.y; g_[2] = ta.z; g_[3] = ta.w;
+                    g_[4] = tb4.x; g_[5] = tb4.y; g_[6] = tb4.z; g_[7] = tb4.w;
+                }
+#pragma unroll
+                for (int u = 0; u < C; u++) {
+                    const int t = tb * C + u;
+                    if (t < TSTEPS) wv[tb % NW][u] = rd[t + t / PAD];
+                }
+            };
+            static_for<0, DEPTH>([&](auto d) { if (decltype(d)::value < NB) fetch_block(decltype(d)::value); });
+            static_for<0, NB>([&](auto tbc) {
+                constexpr int tb = decltype(tbc)::value;
+                if (tb + DEPTH < NB) fetch_block(tb + DEPTH);
+                static_for<0, C / 2>([&](auto uc) {
+                    constexpr int u = 2 * decltype(uc)::value;
+                    constexpr int t = tb * C + u;              /* positions t and t + 1 */
+                    if constexpr (t < TSTEPS) {
+                        constexpr bool a0 = t < NTAPS, a1 = t >= C && t - C < NTAPS;                  /* symbol 0 / 1 at t */
+                        constexpr bool b0 = t + 1 < NTAPS, b1 = t + 1 >= C && t + 1 - C < NTAPS && t + 1 < TSTEPS;   /* at t + 1 */
+                        const v2f va = v2f{wv[tb % NW][u].x, wv[tb % NW][u].y};
+                        const v2f vb = v2f{wv[tb % NW][u + 1].x, wv[tb % NW][u + 1].y};
+                        v2f pa0, pa1, pb0, pb1;    /* re*tap, im*tap (rrc_fir.c:24-25) */
+                        if constexpr (a0) pa0 = va * tg[tb % NG][u];
+                        if constexpr (a1) pa1 = va * tg[(tb - 1 + NG) % NG][u];
+                        if constexpr (b0) pb0 = vb * tg[tb % NG][u + 1];
+                        if constexpr (b1) pb1 = vb * tg[(tb - 1 + NG) % NG][u + 1];
+                        if constexpr (a0 && a1 && b0 && b1) {
+                            asm volatile("" : "+v"(pa0), "+v"(pa1), "+v"(pb0), "+v"(pb1));
+                        } else {
+                            if constexpr (a0) asm volatile("" : "+v"(pa0));
+                            if constexpr (a1) asm volatile("" : "+v"(pa1));
+                            if constexpr (b0) asm volatile("" : "+v"(pb0));
+                            if constexpr (b1) asm volatile("" : "+v"(pb1));
+                        }
+                        if constexpr (a0) ac[0] = ac[0] + pa0;
+                        if constexpr (a1) ac[1] = ac[1] + pa1;
+                        if constexpr (b0) ac[0] = ac[0] + pb0;
+                        if constexpr (b1) ac[1] = ac[1] + pb1;
+                        asm volatile("" : "+v"(ac[0]), "+v"(ac[1]));
+                    }
+                });
+            });
+        } else {
+            ac[0] = v2f{0.7f, 0.3f}; ac[1] = v2f{0.7f, 0.3f};
+        }
+        tick(3);
+        /* ring slot c % DR is free once chunk c - DR has been consumed, and that chunk's symbols leave first */
+        const int g = UF * U.u + fl, frame = f0 + g;
+        const bool mine = g < G && frame < a.nframes;     /* this lane's frame exists (rings have G rows) */
+        if (c >= DR) {
+            if (!wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag)) return false;
+            tick(0);
+            if (mine) flush_records<GM, R>(a, zring, dring, g, frame, q, c - DR);
+            tick(1);
+        }
+        if (g < G) {
+            float2 *dw = dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                dw[r] = fir_gain(make_float2(ac[r].x, ac[r].y));
+        }
+        if (lane == 0) st_release(&sm->ready[U.u], c + 1);
+        tick(4);
+        return true;
+    };
+
+    float4 pre[UF][NLD];
+    prefetch(un[0], pre, 0);
+    bool ok = true;
+    tick(-1);
+    for (int c = 0; c < nchunks && ok; c++) {
+        static_for<0, NUW>([&](auto uic) {
+            constexpr int ui = decltype(uic)::value, nx = (ui + 1) % NUW;
+            constexpr bool last_unit = ui + 1 == NUW;
+            if (ok) ok = run_unit(un[ui], pre, c, un[nx], !last_unit || c + 1 < nchunks, last_unit ? c + 1 : c);
+        });
+    }
+    if (ok) {
+        ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
+        if (ok)
+#pragma unroll
+            for (int ui = 0; ui < NUW; ui++) {
+                const int g = UF * un[ui].u + fl, frame = f0 + g;
+                for (int c = max(0, nchunks - DR); c < nchunks; c++)
+                    if (g < G && frame < a.nframes) flush_records<GM, R>(a, zring, dring, g, frame, q, c);
+            }
+    }
+    if (!ok && lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
+#ifdef QPSK_PIPE_PROFILE
+    if (prof && lane == 0)
+        printf("FIR wave %d (%d units): %d chunks; cycles per chunk: wait for the loop %llu, flush %llu, window staging %llu, "
+               "filter %llu, ring hand-over %llu\n", widx, NUW, nchunks, tacc[0] / nchunks, tacc[1] / nchunks, tacc[2] / nchunks,
+               tacc[3] / nchunks, tacc[4] / nchunks);
+#endif
+}
+
+__global__ void __launch_bounds__(pipe2::MAX_THREADS)
+rx_pipe2_kernel(FusedArgs a, int nfir, int *status)
+{
+    using namespace pipe2;
+    using GM = GeomNarrow;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Smem *sm = reinterpret_cast<Smem *>(smem_raw);
+    const int G = a.G;                                   /* frames of a workgroup (even unless the batch is smaller) */
+    const int NU = (G + UF - 1) / UF;                     /* units */
+    float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));      /* [nfir][UF][WS] */
+    float2 *dring = win + (size_t)nfir * UF * WS;                            /* [G][DSTRIDE] */
+    float *zring = reinterpret_cast<float *>(dring + (size_t)G * GM::DSTRIDE);   /* [G*nbw][ZSTRIDE] */
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f0 = blockIdx.x * G;
+    const int nchunks = (a.nsym + S - 1) / S;
+
+    for (int i = tid; i < 128; i += blockDim.x)
+        sm->taps[i] = i < NTAPS ? a.taps[i] : 0.0f;
+    if (tid < MAX_WAVES) sm->ready[tid] = 0;
+    if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
+    __syncthreads();
+
+    if (wave == 0) {
+        costas_wave<GM>(a, sm, dring, zring, G, f0, lane, nchunks, status);   /* a.mixed == 2: lane g waits on ready[g / 2] */
+        return;
+    }
+    if ((wave & 3) == 0) return;                          /* would share the serial wave's SIMD */
+    const int widx = wave - 1 - wave / 4;                 /* FIR wave index 0 .. nfir-1 */
+    if (widx >= nfir || widx >= NU) return;
+    float2 *mywin = win + (size_t)widx * UF * WS;
+    if (MAX_UW >= 3 && widx + 2 * nfir < NU)
+        fir_wave2<(MAX_UW >= 3 ? 3 : 1)>(a, sm, mywin, dring, zring, G, widx, nfir, f0, lane, nchunks, status);
+    else if (widx + nfir < NU)
+        fir_wave2<2>(a, sm, mywin, dring, zring, G, widx, nfir, f0, lane, nchunks, status);
+    else
+        fir_wave2<1>(a, sm, mywin, dring, zring, G, widx, nfir, f0, lane, nchunks, status);
+}
+
+size_t pipe2_lds_bytes(int G, int nfir, int nbw)
+{
+    using GM = GeomNarrow;
+    size_t b = sizeof(Smem) + sizeof(float2) * ((size_t)nfir * pipe2::UF * pipe2::WS + (size_t)G * GM::DSTRIDE) +
+               sizeof(float) * (size_t)G * nbw * GM::ZSTRIDE;
+    return (b + 15) & ~(size_t)15;
+}
+
+int pipe2_max_fir(void) { return pipe2::MAX_FIR; }
+int pipe2_max_frames(void) { return pipe2::UF * pipe2::MAX_UNITS; }
+int pipe2_max_units_per_wave(void) { return pipe2::MAX_UW; }
+
+/* G frames per workgroup (at most 32, G * nbw <= 64), nfir FIR waves (units / 2 rounded up .. 9) */
+int launch_rx_pipe2(const FusedArgs &a0, int G, int nfir, int *status, hipStream_t s)
+{
+    using namespace pipe2;
+    FusedArgs a = a0;
+    const int NU = (G + UF - 1) / UF;
+    if (G < 1 || G > UF * MAX_UNITS || G * a.nbw > 64 || nfir < 1 || nfir > MAX_FIR || nfir * MAX_UW < NU ||
+        pipe2_lds_bytes(G, nfir, a.nbw) > (size_t)MAX_LDS_BYTES)
+        return (int)hipErrorInvalidValue;
+    a.G = G;
+    a.mixed = 2;                                          /* the serial wave's lane for frame g waits on ready[g / 2] */
+    const int blocks = (a.nframes + G - 1) / G;
+    const int hw = nfir + 1 + (nfir - 1) / 3;             /* FIR wave k is hardware wave k + 1 + k/3 */
+    hipLaunchKernelGGL(rx_pipe2_kernel, dim3(blocks), dim3(64 * hw), pipe2_lds_bytes(G, nfir, a.nbw), s, a, nfir, status);
+    return (int)hipGetLastError();
 }
 
 /* frames of a workgroup with NF FIR waves */
@@ -838,6 +1197,9 @@ int prepare_pipe_kernel(void)
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomWide>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_pipe2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomNarrow>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);

@@ -44,7 +44,7 @@ _LIB = None
 # every symbol include/qpsk_hip.h declares (tests check that the library exports all of them)
 API_SYMBOLS = [
     "qpsk_last_error", "qpsk_version", "qpsk_device_count", "qpsk_params_default", "qpsk_ctx_create",
-    "qpsk_ctx_destroy", "qpsk_ctx_sync", "qpsk_ctx_set_stream", "qpsk_ctx_cycles", "qpsk_ctx_nsym",
+    "qpsk_ctx_destroy", "qpsk_ctx_sync", "qpsk_ctx_set_stream", "qpsk_ctx_set_tuning", "qpsk_ctx_cycles", "qpsk_ctx_nsym",
     "qpsk_ctx_get_taps", "qpsk_ctx_get_gains", "qpsk_ctx_set_taps", "qpsk_ctx_set_loop", "qpsk_rx_batch",
     "qpsk_rx_batch_bw", "qpsk_rrc_fir_batch", "qpsk_timing_hist_batch", "qpsk_costas_batch", "qpsk_fft_batch",
     "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
@@ -90,6 +90,7 @@ def load():
     L.qpsk_ctx_destroy.restype = None
     L.qpsk_ctx_sync.argtypes = [vp]
     L.qpsk_ctx_set_stream.argtypes = [vp, vp]
+    L.qpsk_ctx_set_tuning.argtypes = [vp, C.c_char_p, i32]
     L.qpsk_ctx_cycles.argtypes = [vp]
     L.qpsk_ctx_nsym.argtypes = [vp]
     L.qpsk_ctx_get_taps.argtypes = [vp, C.POINTER(f32)]
@@ -165,6 +166,17 @@ class Modem:
 
     def sync(self):
         self._check(self.L.qpsk_ctx_sync(self.h))
+
+    def tune(self, **kw):
+        """Kernel-geometry selection (tests, measurements): m.tune(pipe_nf=3, pipe_wide=0); None = library's choice.
+        Keys are the QPSK_* names of qpsk_ctx_set_tuning() in lower case without the prefix."""
+        for k, v in kw.items():
+            self._check(self.L.qpsk_ctx_set_tuning(self.h, ("QPSK_" + k.upper()).encode(), -1 if v is None else int(v)))
+
+    def set_stream(self, stream):
+        """Enqueue this context's work on another HIP stream (a torch.cuda.Stream or a raw handle; None = default)."""
+        s = None if stream is None else C.c_void_p(getattr(stream, "cuda_stream", stream))
+        self._check(self.L.qpsk_ctx_set_stream(self.h, s))
 
     # ---- configuration
     @property

@@ -21,6 +21,14 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def local_device(local_rank, device_count):
+    """The GPU of a rank: its own (LOCAL_RANK) on a node with one GPU per rank; on a box with fewer GPUs than
+    ranks (a rehearsal: results are the same, timings are not a scaling measurement) ranks share round-robin."""
+    if device_count <= 0:
+        raise ValueError("no GPU")
+    return local_rank % device_count
+
+
 def init_distributed(backend, device=None):
     """Returns the torch.distributed module (initialised) or None for a single process."""
     rank, _, world = env_rank_world()

@@ -22,7 +22,8 @@ def run_bench(*args):
 def test_bench_defaults_are_the_contract_defaults():
     """no flags = 1 GPU and a K/W that let the clocks settle (a step is 0.2 ms)"""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert '"--gpus", type=int, default=1' in src
+    assert "args.gpus = int(env_world) if env_world else 1" in src      # no flag, no WORLD_SIZE: one GPU
+    assert "FRAMES_1GPU = 4096" in src and "FRAMES_PER_GPU_SHARDED = 8192" in src   # configs[1] / configs[3] shapes
     assert '"--steps", type=int, default=200' in src and '"--warmup", type=int, default=20' in src
 
 

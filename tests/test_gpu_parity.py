@@ -117,34 +117,44 @@ def test_rx_batch_fft_timing(oracle, fs, rs, L, F):
     assert np.all(want["index"][:F - 2] == 126 % m.cycles)
 
 
-def test_rx_batch_tilings_agree(oracle, monkeypatch):
+def test_rx_batch_tilings_agree(oracle):
     """results do not depend on how frames are grouped into workgroups / chunks"""
     fs, rs, L, F = 19200.0, 2400.0, 2048, 50
     m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=4)
     x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=3)
     want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=4, want_costas=True)
     for G, S in [(1, 8), (3, 24), (16, 32), (64, 8), (7, 64)]:
-        monkeypatch.setenv("QPSK_FUSED_G", str(G))
-        monkeypatch.setenv("QPSK_FUSED_S", str(S))
+        m.tune(fused_g=G)
+        m.tune(fused_s=S)
         got = m.rx_batch(x, want_costas=True)
         m.sync()
         assert_batch_equal(got, want)
 
 
 @pytest.mark.parametrize("L,mode", [(2048, TIMING_FIXED), (1000, TIMING_FIXED), (2048, TIMING_HIST), (16384, TIMING_FIXED)])
-def test_pipeline_geometries_agree(oracle, monkeypatch, L, mode):
-    """the two geometries of the pipeline kernel (4 or 2 symbols per FIR lane: chunks of 64 or 32 symbols, up to 16
-    or 32 frames per workgroup) and every number of FIR waves give the oracle's bits; frame counts are ragged
-    against both"""
+def test_pipeline_geometries_agree(oracle, L, mode):
+    """every layout of the pipeline kernels gives the oracle's bits: rx_pipe2_kernel (two-frame units, 1..32 frames
+    per workgroup, 1..9 FIR waves owning one or two units each) and the two geometries of rx_fused_pipe_kernel (4 or 2
+    symbols per FIR lane, up to 16 or 32 frames per workgroup); frame counts are ragged against all of them"""
     fs, rs, F = 19200.0, 2400.0, 75
     m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=mode, fixed_index=5)
     x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=L, noise=0.05)
     x[7] = 0.0
     want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=mode, fixed_index=5, want_costas=True)
+    m.tune(pipe_v=2)
+    for G, nf in ((None, None), (1, 1), (2, 1), (3, 1), (3, 2), (5, 3), (16, 8), (16, 4), (17, 9), (18, 5), (31, 8), (32, 9), (32, 8)):
+        m.tune(pipe_g=G, pipe_nf=nf)
+        got = m.rx_batch(x, want_costas=True)
+        m.sync()
+        assert_batch_equal(got, want)
+        got = m.rx_batch(x[:33], want_costas=False)
+        m.sync()
+        assert bits_equal(cpu(got["sym"]), want["sym"][:33]) and bits_equal(cpu(got["freq"]), want["freq"][:33])
+    m.tune(pipe_v=1, pipe_g=None, pipe_nf=None)
     for wide, nfs in ((0, (1, 2, 3, 4)), (1, (1, 3, 5, 8))):
         for nf in nfs:
-            monkeypatch.setenv("QPSK_PIPE_WIDE", str(wide))
-            monkeypatch.setenv("QPSK_PIPE_NF", str(nf))
+            m.tune(pipe_wide=wide)
+            m.tune(pipe_nf=nf)
             got = m.rx_batch(x, want_costas=True)
             m.sync()
             assert_batch_equal(got, want)
@@ -153,9 +163,9 @@ def test_pipeline_geometries_agree(oracle, monkeypatch, L, mode):
             assert bits_equal(cpu(got["sym"]), want["sym"][:33]) and bits_equal(cpu(got["freq"]), want["freq"][:33])
     # nf = 4 above ran with two lane mappings in one workgroup (16 frames: 12 at 4 symbols per lane, 4 at 2);
     # the A/B variant with one mapping for all four FIR waves
-    monkeypatch.setenv("QPSK_PIPE_WIDE", "0")
-    monkeypatch.setenv("QPSK_PIPE_NF", "4")
-    monkeypatch.setenv("QPSK_PIPE_DBG", "128")
+    m.tune(pipe_wide=0)
+    m.tune(pipe_nf=4)
+    m.tune(pipe_dbg=128)
     got = m.rx_batch(x, want_costas=True)
     m.sync()
     assert_batch_equal(got, want)
@@ -244,10 +254,10 @@ def test_full_size_config2_properties(oracle):
     assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
 
 
-def test_full_size_config4_shard_properties(oracle, monkeypatch):
-    """BASELINE config 4's per-GPU share (8192 frames x 16384 samples, 1 GiB): this batch size takes the wide
-    geometry by itself; (a) a spread sample of frames equals the oracle bit for bit, (b) the narrow geometry
-    forced on the same batch gives the same bits everywhere, (c) every loop ends on the +50 Hz offset."""
+def test_full_size_config4_shard_properties(oracle):
+    """BASELINE config 4's per-GPU share (8192 frames x 16384 samples, 1 GiB), which rx_pipe2_kernel takes as 256
+    workgroups of 32 frames: (a) a spread sample of frames equals the oracle bit for bit, (b) the 16-frame workgroups
+    of rx_fused_pipe_kernel (two rounds) give the same bits everywhere, (c) every loop ends on the +50 Hz offset."""
     import torch
     import bench
     fs, rs, L, F = bench.FS, bench.RS, 16384, 8192
@@ -260,7 +270,7 @@ def test_full_size_config4_shard_properties(oracle, monkeypatch):
                            fixed_index=bench.FIXED_INDEX)
     for k in ("sym", "phase", "freq", "hz"):
         assert bits_equal(cpu(a[k])[pick], want[k]), k
-    monkeypatch.setenv("QPSK_PIPE_WIDE", "0")
+    m.tune(pipe_v=1, pipe_wide=0)
     b = m.rx_batch(x)
     m.sync()
     for k in ("sym", "phase", "freq"):
@@ -269,7 +279,7 @@ def test_full_size_config4_shard_properties(oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", [TIMING_FIXED, TIMING_HIST])
-def test_smallest_frames(oracle, monkeypatch, mode):
+def test_smallest_frames(oracle, mode):
     """frames of one symbol up to just over one chunk, one to three frames per call, both pipeline geometries:
     the ragged ends of every loop in the kernels"""
     fs, rs = 19200.0, 2400.0
@@ -278,14 +288,14 @@ def test_smallest_frames(oracle, monkeypatch, mode):
         for F in (1, 3):
             x = random_frames(F, L, seed=L + F, scale=0.7)
             want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=mode, fixed_index=7, want_costas=True)
-            for wide in (0, 1):
-                monkeypatch.setenv("QPSK_PIPE_WIDE", str(wide))
+            for v, wide in ((2, 0), (1, 0), (1, 1)):
+                m.tune(pipe_v=v, pipe_wide=wide)
                 got = m.rx_batch(x, want_costas=True)
                 m.sync()
                 assert_batch_equal(got, want)
 
 
-def test_randomised_configurations(oracle, monkeypatch):
+def test_randomised_configurations(oracle):
     """a fixed-seed sweep over frame sizes, frame counts, amplitudes, loop bandwidths, clamps, timing modes and
     pipeline geometries: every output bit against the oracle (rare paths: 2 pi wraps, active clamp, exact zeros,
     ragged chunks and workgroups)"""
@@ -310,8 +320,10 @@ def test_randomised_configurations(oracle, monkeypatch):
         m = modem(fs=fs, rs=rs, frame_size=L, loop_bw=bw, min_freq=lo, max_freq=hi, timing_mode=mode, fixed_index=idx)
         want = oracle.rx_batch(x, fs, rs, loop_bw=bw, min_freq=lo, max_freq=hi, timing_mode=mode, fixed_index=idx,
                                want_costas=True)
-        monkeypatch.setenv("QPSK_PIPE_WIDE", str(case % 2))
-        monkeypatch.setenv("QPSK_PIPE_NF", str(1 + case % 8))
+        if case % 3 == 0:     # a third of the cases through rx_fused_pipe_kernel's two geometries
+            m.tune(pipe_v=1, pipe_wide=case % 2, pipe_nf=1 + case % 8)
+        else:
+            m.tune(pipe_v=2, pipe_g=1 + (case * 7) % 32, pipe_nf=1 + case % 9)
         got = m.rx_batch(x, want_costas=True)
         m.sync()
         try:
@@ -321,7 +333,7 @@ def test_randomised_configurations(oracle, monkeypatch):
                 case, L, F, scale, bw, lo, hi, mode, idx, e))
 
 
-def test_two_loops_per_frame_in_the_wide_geometry(oracle, monkeypatch):
+def test_two_loops_per_frame_in_the_wide_geometry(oracle):
     """several loops per frame in the 32-symbol-chunk geometry (the host sheds FIR waves until the record rings
     of all loops fit the LDS)"""
     fs, rs, L, F = 19200.0, 2400.0, 2048, 45
@@ -329,7 +341,7 @@ def test_two_loops_per_frame_in_the_wide_geometry(oracle, monkeypatch):
     m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=3)
     x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=20.0, base_seed=77, noise=0.05)
     want = oracle.rx_batch_bw(x, fs, rs, bws, timing_mode=TIMING_FIXED, fixed_index=3)
-    monkeypatch.setenv("QPSK_PIPE_WIDE", "1")
+    m.tune(pipe_v=1, pipe_wide=1)
     got = m.rx_batch_bw(x, bws)
     m.sync()
     assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
@@ -411,13 +423,13 @@ def test_fir_golden():
 
 @pytest.mark.parametrize("cycles,L,generic", [(8, 1024, 0), (8, 1024, 1), (4, 512, 0), (5, 1000, 0), (8, 16384, 0),
                                                (8, 16384, 1), (8, 1032, 0), (8, 128, 0)])
-def test_timing_histogram(oracle, monkeypatch, cycles, L, generic):
+def test_timing_histogram(oracle, cycles, L, generic):
     """index AND the summed histograms hist_i + hist_q (qpsk.c:175) for both scans (the CYCLES = 8 kernel and the
     generic one, which also takes the frames that are not whole 128-sample tiles)"""
-    if generic:
-        monkeypatch.setenv("QPSK_HIST_GENERIC", "1")
     rs = 2400.0
     m = modem(fs=rs * cycles, rs=rs, frame_size=L)
+    if generic:
+        m.tune(hist_generic=1)
     x, _ = make_frames(37, L, cycles, m.taps, rs * cycles, noise=0.1, base_seed=cycles)
     x[0] = 0.0
     x[1] = random_frames(1, L, seed=5)[0]
@@ -673,12 +685,12 @@ def test_streams_with_fft_timing(oracle):
 
 
 @pytest.mark.parametrize("generic", [0, 1])
-def test_streams_cplx_vs_oracle(oracle, monkeypatch, generic):
+def test_streams_cplx_vs_oracle(oracle, generic):
     """generic = 1: the barrier-synchronised kernels (decimate_kernel + costas_kernel) instead of the pipeline"""
-    if generic:
-        monkeypatch.setenv("QPSK_FUSED_GENERIC", "1")
     fs, rs, L, S = 19200.0, 2400.0, 1024, 9
     m = modem(fs=fs, rs=rs, frame_size=L)
+    if generic:
+        m.tune(fused_generic=1)
     m.streams_reset(S)
     om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
     x, _ = make_frames(S, L * 5, 8, m.taps, fs, offset_hz=30.0, base_seed=17, noise=0.02)
@@ -691,3 +703,79 @@ def test_streams_cplx_vs_oracle(oracle, monkeypatch, generic):
             assert cpu(o["index"])[s] == om[s].index
             assert bits_equal(cpu(o["sym"][s]), om[s].symbols) and bits_equal(cpu(o["costas"][s]), om[s].costas_frame)
             assert cpu(o["phase"])[s] == om[s].phase and cpu(o["freq"])[s] == om[s].freq
+
+
+# ------------------------------------------------------------------ robustness of the product library
+def test_environment_cannot_change_results(oracle, monkeypatch):
+    """the ablation bits of QPSK_PIPE_DBG (1: skip the filter arithmetic, 2: skip the recurrence) exist only in the
+    measurement build; the product library returns the oracle's bits whatever the environment or the tuning call says"""
+    fs, rs, L, F = 19200.0, 2400.0, 2048, 70
+    monkeypatch.setenv("QPSK_PIPE_DBG", "3")       # read by qpsk_ctx_create()
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=5, noise=0.03)
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=6, want_costas=True)
+    got = m.rx_batch(x, want_costas=True)
+    m.sync()
+    assert_batch_equal(got, want)
+    m.tune(pipe_dbg=3)
+    got = m.rx_batch(x, want_costas=True)
+    m.sync()
+    assert_batch_equal(got, want)
+    import qpsk_amd
+    with pytest.raises(qpsk_amd.QpskError):
+        m.tune(no_such_knob=1)
+
+
+@pytest.mark.parametrize("generic", [0, 1])
+def test_huge_amplitude_is_an_error_not_a_hang(oracle, generic):
+    """frames of amplitude 1e12: alpha*e reaches ~1e11, where the reference's unbounded phase_wrap() (costas_loop.c:61-67)
+    never returns ((float)((double)p - TAU) == p from 2^27 on).  The kernels bound the wrap and the call fails with
+    QPSK_ERR_RANGE at the next synchronisation; the context stays usable and ordinary frames still give the oracle's bits"""
+    import qpsk_amd
+    fs, rs, L, F = 19200.0, 2400.0, 1024, 20
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    if generic:
+        m.tune(fused_generic=1)
+    x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=8)
+    bad = x.copy()
+    bad[3] *= np.float32(1e12)
+    m.rx_batch(bad)
+    with pytest.raises(qpsk_amd.QpskError, match="-6"):
+        m.sync()
+    got = m.rx_batch(x)
+    m.sync()                                         # the flag was cleared by the failed sync
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=6)
+    assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
+    # phases the reference does wrap (a few hundred turns per step) are wrapped exactly as it does
+    big = (x * np.float32(3e3)).astype(np.float32)
+    got = m.rx_batch(big)
+    m.sync()
+    want = oracle.rx_batch(big, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=6)
+    assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
+
+
+def test_caller_stream_ordering_contract(oracle):
+    """include/qpsk_hip.h, "Stream ordering": the library enqueues on the context's stream and nothing else orders it
+    against the caller's other streams.  Here the context runs on a NON-default torch stream, buffers are produced and
+    recycled by torch's stream-ordered allocator under that same stream (the contract kept), with allocations in between
+    calls: results are the oracle's.  (Round 1's abort in bench.py was this contract broken: a private library stream
+    wrote output buffers whose memory torch had recycled from tensors that queued torch kernels still had to read.)"""
+    import torch
+    fs, rs, L, F = 19200.0, 2400.0, 2048, 64
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    xh, _ = make_frames(F, L, 8, m.taps, fs, base_seed=21, noise=0.02)
+    want = oracle.rx_batch(xh, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=6)
+    side = torch.cuda.Stream()
+    m.set_stream(side)
+    with torch.cuda.stream(side):
+        for it in range(4):
+            x = torch.from_numpy(xh).cuda(non_blocking=True)          # produced on `side`
+            junk = [torch.randn(1 << 20, device="cuda") for _ in range(3)]   # allocator traffic on `side`
+            got = m.rx_batch(x)
+            del junk, x                                                # recycled in `side` order: safe
+            junk2 = torch.zeros(1 << 22, device="cuda")
+            side.synchronize()
+            assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
+            del junk2
+    m.sync()
+    m.set_stream(None)

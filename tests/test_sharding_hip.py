@@ -1,0 +1,121 @@
+"""The N > 1 path THROUGH THE HIP LIBRARY: two fresh processes (one context each, device LOCAL_RANK % device_count, so
+both land on the one GPU of a 1-GPU box) demodulate their contiguous shards with qpsk_amd.Modem, gather them over
+gloo, and rank 0 compares the gathered symbols / freq / phase bit for bit with (a) the single-process HIP result over
+the whole batch and (b) the oracle.  Frames shard freely because all state is per modem (reference qpsk.c:36-53,
+costas_loop.c:13-23); SURVEY 8(e).  tests/test_sharding_gloo.py covers the same logic on CPU with the oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch
+import qpsk_amd
+from qpsk_amd.shard import env_rank_world, init_distributed, local_device, shard_range
+from sigutil import make_frames
+rank, local, world = env_rank_world()
+dist = init_distributed("gloo")
+assert dist is not None and dist.get_world_size() == world == 2
+assert torch.cuda.is_available()
+dev = local_device(local, torch.cuda.device_count())
+torch.cuda.set_device(dev)
+FS, RS, L, TOTAL = 19200.0, 2400.0, 2048, 37          # 37 frames: uneven split 18 + 19
+m = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=6, device=dev)
+lo, hi = shard_range(TOTAL, rank, world)
+x, _ = make_frames(hi - lo, L, 8, m.taps, FS, base_seed=99, first_frame=lo, noise=0.05)
+dist.barrier()
+out = m.rx_batch(x)
+m.sync()
+mine = (lo, hi, out["sym"].cpu().numpy(), out["freq"].cpu().numpy(), out["phase"].cpu().numpy())
+gathered = [None] * world
+dist.all_gather_object(gathered, mine)
+if rank == 0:
+    gathered.sort(key=lambda g: g[0])
+    assert gathered[0][0] == 0 and gathered[-1][1] == TOTAL and gathered[0][1] == gathered[1][0]
+    sym = np.concatenate([g[2] for g in gathered]); freq = np.concatenate([g[3] for g in gathered]); phase = np.concatenate([g[4] for g in gathered])
+    xa, _ = make_frames(TOTAL, L, 8, m.taps, FS, base_seed=99, noise=0.05)
+    one = m.rx_batch(xa)            # the whole batch in this one process, same library
+    m.sync()
+    ok_hip = (np.array_equal(sym, one["sym"].cpu().numpy())
+              and np.array_equal(freq.view(np.uint32), one["freq"].cpu().numpy().view(np.uint32))
+              and np.array_equal(phase.view(np.uint32), one["phase"].cpu().numpy().view(np.uint32)))
+    from oracle.pyoracle import Oracle, TIMING_FIXED
+    want = Oracle().rx_batch(xa, FS, RS, timing_mode=TIMING_FIXED, fixed_index=6)
+    ok_orc = (np.array_equal(sym, want["sym"]) and np.array_equal(freq.view(np.uint32), want["freq"].view(np.uint32))
+              and np.array_equal(phase.view(np.uint32), want["phase"].view(np.uint32)))
+    print("HIP_SHARD", ok_hip, ok_orc, dev)
+dist.barrier()
+m.close()
+dist.destroy_process_group()
+'''
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_the_hip_library(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "HIP_SHARD True True" in outs[0], outs[0]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) must start two ranks itself and say n_gpus = 2;
+    on a 1-GPU box both ranks share the GPU (a rehearsal of the launch path, not a scaling number)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--frames", "64", "--frame-size", "2048"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 64 and d["config"]["frames_total"] == 128
+    assert d["parity"]["symbol_mismatches"] == 0 and "cpu_baseline" not in d
+
+
+def test_bench_gpus_flag_is_not_ignored():
+    """CPU side of the same contract: without a GPU `--gpus 2` still starts two ranks (both fail loudly: no CPU path)
+    and the parent exits non-zero; a --gpus that contradicts WORLD_SIZE is refused."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_gpus_2_starts_two_ranks")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "ranks failed: [(0, 1), (1, 1)]" in r.stderr, r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

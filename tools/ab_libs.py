@@ -56,9 +56,16 @@ def main():
             torch.cuda.synchronize()
             if r >= 3:
                 times[i].append(e0.elapsed_time(e1))
-    for p, t in zip(args.libs, times):
+    ref = None
+    for p, t, m in zip(args.libs, times, modems):
         t.sort()
-        print("%-40s median %.4f ms   min %.4f   p90 %.4f" % (os.path.basename(p), statistics.median(t), t[0], t[int(len(t) * .9)]))
+        m.rx_batch_raw(x, args.frames, sym, fr, ph)       # builds differ in layout and schedule, never in results
+        torch.cuda.synchronize()
+        got = (sym.clone(), fr.clone(), ph.clone())
+        ref = ref or got
+        same = all(torch.equal(a.view(torch.uint8), b.view(torch.uint8)) for a, b in zip(got, ref))
+        print("%-40s median %.4f ms   min %.4f   p90 %.4f   %s" % (os.path.basename(p), statistics.median(t), t[0], t[int(len(t) * .9)],
+                                                                  "same bits as the first" if same else "RESULT DIFFERS FROM THE FIRST"))
 
 
 if __name__ == "__main__":

@@ -21,15 +21,21 @@ import bench  # noqa: E402
 import qpsk_amd  # noqa: E402
 
 dev = torch.device("cuda", 0)
-for frames, tag in ((4096, "narrow"), (8192, "wide")):
+settings = [dict(pipe_v=2), dict(pipe_v=1)] if len(sys.argv) < 2 else [dict(kv.split("=") for kv in a.split()) for a in sys.argv[1:]]
+for frames in (4096, 8192):
     m = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=6)
     x = bench.synth_frames_gpu(torch, dev, frames, m.taps, seed=1)
     sym = torch.empty((frames, m.nsym), dtype=torch.uint8, device=dev)
     fr = torch.empty((frames,), dtype=torch.float32, device=dev)
     ph = torch.empty_like(fr)
-    os.environ["QPSK_PIPE_DBG"] = "32"
-    print("==== %s geometry, %d frames" % (tag, frames), flush=True)
-    m.rx_batch_raw(x, frames, sym, fr, ph)
-    torch.cuda.synchronize()
-    os.environ.pop("QPSK_PIPE_DBG")
+    for st in settings:
+        m.tune(**{k: int(v) for k, v in st.items()})
+        for _ in range(3):
+            m.rx_batch_raw(x, frames, sym, fr, ph)
+        torch.cuda.synchronize()
+        m.tune(pipe_dbg=32)
+        print("==== %d frames, %s" % (frames, st), flush=True)
+        m.rx_batch_raw(x, frames, sym, fr, ph)
+        torch.cuda.synchronize()
+        m.tune(pipe_dbg=0)
     del x
