@@ -61,17 +61,19 @@ struct DevBuf {
 struct Tuning {
     int fused_g = -1, fused_s = -1, fused_lds = -1;   /* generic chunked kernel: frames per workgroup, symbols per chunk, LDS budget */
     int generic = -1;                                 /* 1: the barrier-synchronised generic kernels instead of the pipeline */
-    int pipe_wide = -1, pipe_nf = -1;                 /* pipeline kernel: geometry, FIR waves per workgroup */
+    int pipe_nf = -1;                                 /* rx_fused_pipe_kernel: FIR waves per workgroup */
     int pipe_v = -1, pipe_g = -1;                     /* 1: rx_fused_pipe_kernel, 2: rx_pipe2_kernel; frames per workgroup of the latter */
+    int layout_lo = -1, layout_hi = -1;               /* rx_pipe2_kernel: units per hardware wave, 4 bits each (waves 1-5 / 6-11) */
     int pipe_variant = -1;                            /* pipeline kernel: layout bits (kernels.h, FusedArgs::dbg) */
     int hist_generic = -1;                            /* 1: the generic timing scan instead of the CYCLES = 8 one */
 };
 
 static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
     {"QPSK_FUSED_G", &Tuning::fused_g},       {"QPSK_FUSED_S", &Tuning::fused_s},     {"QPSK_FUSED_LDS", &Tuning::fused_lds},
-    {"QPSK_FUSED_GENERIC", &Tuning::generic}, {"QPSK_PIPE_WIDE", &Tuning::pipe_wide}, {"QPSK_PIPE_NF", &Tuning::pipe_nf},
+    {"QPSK_FUSED_GENERIC", &Tuning::generic}, {"QPSK_PIPE_NF", &Tuning::pipe_nf},
     {"QPSK_PIPE_DBG", &Tuning::pipe_variant}, {"QPSK_HIST_GENERIC", &Tuning::hist_generic},
     {"QPSK_PIPE_V", &Tuning::pipe_v},         {"QPSK_PIPE_G", &Tuning::pipe_g},
+    {"QPSK_PIPE_LAYOUT_LO", &Tuning::layout_lo}, {"QPSK_PIPE_LAYOUT_HI", &Tuning::layout_hi},
 };
 
 /* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
@@ -80,7 +82,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
 #ifdef QPSK_PIPE_PROFILE
 static const int PIPE_VARIANT_MASK = ~0;
 #else
-static const int PIPE_VARIANT_MASK = 4 | 8 | 64 | 128;
+static const int PIPE_VARIANT_MASK = 4 | 8 | 64 | 128 | 256 | 512 | 1024;
 #endif
 
 struct qpsk_ctx {
@@ -483,9 +485,12 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
     /* the pipeline kernel (rx_fused.hip) is built for CYCLES = 8, 16-byte aligned frames and an index
      * below CYCLES; everything else takes the generic chunked kernel (kernels.hip) */
     const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 &&
-                         ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames(1, false) <= 64 &&
+                         ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames(1) <= 64 &&
                          tuned(c->tune.generic, 0) == 0;
-    const int pipe_v = tuned(c->tune.pipe_v, 1);   /* rx_pipe2_kernel stays opt-in until it beats the 16-frame workgroups */
+    /* Two pipeline kernels [measured, DESIGN.md 4.1]: up to 16 frames per CU the recurrence is the limit and the
+     * 16-frame workgroups of rx_fused_pipe_kernel (serial wave alone on its SIMD, four-symbol FIR lanes) are 2 %
+     * ahead; above that the filter is the limit and rx_pipe2_kernel's 32-frame workgroups win by 20 % */
+    const int pipe_v = tuned(c->tune.pipe_v, nframes > 16 * c->ncu ? 2 : 1);
     if (pipe_ok && pipe_v == 2) {
         /* rx_pipe2_kernel: up to 32 frames per workgroup, one workgroup per CU when the batch allows it */
         int G = (nframes + c->ncu - 1) / c->ncu;
@@ -494,37 +499,43 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
         if (G > pipe2_max_frames()) G = pipe2_max_frames();
         if (G * nbw > 64) G = 64 / nbw;
         if (G < 1) G = 1;
-        const int NU = (G + 1) / 2;
-        int nfir = NU < pipe2_max_fir() ? NU : pipe2_max_fir();
-        nfir = tuned(c->tune.pipe_nf, nfir);
-        if (nfir > pipe2_max_fir()) nfir = pipe2_max_fir();
-        if (nfir < 1) nfir = 1;
-        while (nfir < pipe2_max_fir() && nfir * pipe2_max_units_per_wave() < NU) nfir++;
-        while (G > 1 && pipe2_lds_bytes(G, nfir, nbw) > (size_t)MAX_LDS_BYTES) G--;   /* many loops per frame: the record rings grow */
-        KERNEL_TRY(launch_rx_pipe2(a, G, nfir, c->d_status, c->stream));
-    } else if (pipe_ok) {
-        /* geometry: the narrow workgroups (16 frames, the serial wave alone on its SIMD) for every batch size; a
-         * batch above 16 frames per CU runs them in rounds.  The wide ones (32 frames, FIR waves beside the serial
-         * wave) were the faster choice for such batches while the serial wave wrote 16-byte records every step
-         * (8192 frames: 0.345 against 0.373 ms); with the phase records it is the other way round (0.379 against
-         * 0.348 ms), so they are kept for QPSK_PIPE_WIDE=1 only -- see rx_fused.hip */
-        auto fits = [&](int nf_, bool wide_) {   /* one lane of the serial wave per (frame, loop); rings grow with the loops */
-            return pipe_frames(nf_, wide_) * nbw <= 64 && pipe_lds_bytes(nf_, nbw, wide_) <= (size_t)MAX_LDS_BYTES;
-        };
-        const bool wide = tuned(c->tune.pipe_wide, 0) != 0 && fits(1, true);
-        const int full = pipe_max_nf(wide);
-        int nf = full;
-        if (!wide) {   /* just enough FIR waves to give every CU one workgroup */
-            nf = 1;
-            while (nf < full && (long long)c->ncu * pipe_frames(nf, false) < nframes) nf++;
+        /* wave layout: the library's (pipe2_default_layout), or the caller's for measurements: 4 bits per hardware wave
+         * = units it owns, waves 1-5 in QPSK_PIPE_LAYOUT_LO, 6-11 in QPSK_PIPE_LAYOUT_HI (their sum fixes G's units) */
+        unsigned long long layout = 0;
+        if (c->tune.layout_lo >= 0 || c->tune.layout_hi >= 0) {
+            layout = ((unsigned long long)(unsigned)tuned(c->tune.layout_lo, 0) << 4) |
+                     ((unsigned long long)(unsigned)tuned(c->tune.layout_hi, 0) << 24);
+            int units = 0, nwin = 0;
+            for (int w = 1; w < 16; w++) { const int cw = (int)((layout >> (4 * w)) & 15); units += cw; nwin += cw != 0; }
+            if (units < 1 || (G + 1) / 2 != units || pipe2_lds_bytes(G, nwin, nbw) > (size_t)MAX_LDS_BYTES)
+                return fail(QPSK_ERR_ARG, "QPSK_PIPE_LAYOUT_*: %d units on %d waves do not match %d frames per workgroup", units, nwin, G);
+        } else {
+            for (;;) {   /* many loops per frame: the record rings grow, fewer frames fit */
+                layout = pipe2_default_layout((G + 1) / 2);
+                int nwin = 0;
+                for (int w = 1; w < 16; w++) nwin += ((layout >> (4 * w)) & 15) != 0;
+                if (layout && pipe2_lds_bytes(G, nwin, nbw) <= (size_t)MAX_LDS_BYTES) break;
+                if (G == 1) return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: %d loops per frame", nbw);
+                G--;
+            }
         }
+        KERNEL_TRY(launch_rx_pipe2(a, G, layout, c->d_status, c->stream));
+    } else if (pipe_ok) {
+        /* 16-frame workgroups (four FIR waves of four frames, fewer when the batch gives a CU fewer frames); a batch
+         * above 16 frames per CU would run them in rounds */
+        auto fits = [&](int nf_) {   /* one lane of the serial wave per (frame, loop); rings grow with the loops */
+            return pipe_frames(nf_) * nbw <= 64 && pipe_lds_bytes(nf_, nbw) <= (size_t)MAX_LDS_BYTES;
+        };
+        const int full = pipe_max_nf();
+        int nf = 1;
+        while (nf < full && (long long)c->ncu * pipe_frames(nf) < nframes) nf++;
         nf = tuned(c->tune.pipe_nf, nf);
         if (nf < 1) nf = 1;
         if (nf > full) nf = full;
-        while (nf > 1 && !fits(nf, wide)) nf--;
-        if (!fits(nf, wide))
-            return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame, wide %d", nf, nbw, (int)wide);
-        KERNEL_TRY(launch_rx_fused_pipe(a, nf, wide, c->d_status, c->stream));
+        while (nf > 1 && !fits(nf)) nf--;
+        if (!fits(nf))
+            return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame", nf, nbw);
+        KERNEL_TRY(launch_rx_fused_pipe(a, nf, c->d_status, c->stream));
     } else {
         KERNEL_TRY(launch_rx_fused(a, c->stream));
     }
@@ -603,9 +614,9 @@ static int costas_over_symbols(qpsk_ctx *c, float *d_symbols, int nframes, int n
     a.dstride = dstride;
     a.status = c->d_status;
     a.dbg = tuned(c->tune.pipe_variant, 0) & PIPE_VARIANT_MASK;
-    int nf = (nframes + c->ncu * pipe_frames(1, false) - 1) / (c->ncu * pipe_frames(1, false));
+    int nf = (nframes + c->ncu * pipe_frames(1) - 1) / (c->ncu * pipe_frames(1));
     if (nf < 1) nf = 1;
-    if (nf > pipe_max_nf(false)) nf = pipe_max_nf(false);
+    if (nf > pipe_max_nf()) nf = pipe_max_nf();
     KERNEL_TRY(launch_costas_pipe(a, nf, c->d_status, c->stream));
     return QPSK_OK;
 }

@@ -23,6 +23,7 @@ struct FusedArgs {
     int mixed;              /* rx_fused_pipe_kernel, set by its launcher: 0 = every FIR wave filters 4 frames, 4 symbols per
                                lane; 1 = 16 frames per workgroup, the last four by two waves of 2 frames with 2 symbols
                                per lane; 2 = every FIR wave 2 frames with 2 symbols per lane (see the kernel) */
+    int share_simd0;        /* rx_pipe2_kernel, set by its launcher: a FIR wave sits beside the serial wave (priorities, see there) */
     const int32_t *index;   /* [nframes] or NULL -> fixed_index */
     int fixed_index;
     int dbg;                /* layout variants of the pipeline kernel, all bit-exact (qpsk_ctx_set_tuning "QPSK_PIPE_DBG"):
@@ -56,19 +57,21 @@ size_t fused_lds_bytes(int G, int S, int cycles, int nbw);
 int prepare_kernels(void);
 int launch_rx_fused(const FusedArgs &a, hipStream_t s);
 /* rx_fused.hip: the producer/consumer pipeline kernel (CYCLES = 8 only) */
-size_t pipe_lds_bytes(int NF, int nbw, bool wide);
-int pipe_frames(int NF, bool wide);    /* frames of a workgroup with NF FIR waves: 4 per wave */
+size_t pipe_lds_bytes(int NF, int nbw);
+int pipe_frames(int NF);               /* frames of a workgroup with NF FIR waves: 4 per wave */
 int pipe_cycles(void);
-int pipe_max_nf(bool wide);            /* FIR waves per workgroup: narrow 4 (16 frames), wide 8 (32 frames) */
+int pipe_max_nf(void);                 /* FIR waves per workgroup: 4 (16 frames) */
 int prepare_pipe_kernel(void);
-int launch_rx_fused_pipe(const FusedArgs &a, int NF, bool wide, int *status, hipStream_t s);
+int launch_rx_fused_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s);
 int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s);
 /* rx_fused.hip: the pipeline kernel for up to 32 frames per workgroup (two-frame units, per-wave windows) */
-size_t pipe2_lds_bytes(int G, int nfir, int nbw);
+size_t pipe2_lds_bytes(int G, int nwin, int nbw);      /* nwin = FIR waves (one window each) */
 int pipe2_max_fir(void);
 int pipe2_max_frames(void);
 int pipe2_max_units_per_wave(void);
-int launch_rx_pipe2(const FusedArgs &a, int G, int nfir, int *status, hipStream_t s);
+int pipe2_max_hw_waves(void);
+unsigned long long pipe2_default_layout(int NU);        /* 4 bits per hardware wave: units it owns; 0 if NU does not fit */
+int launch_rx_pipe2(const FusedArgs &a, int G, unsigned long long layout, int *status, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s);
 int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s);

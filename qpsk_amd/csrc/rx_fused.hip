@@ -23,9 +23,8 @@
  * A full workgroup (16 frames) has three FIR waves of 4 frames (4 symbols per lane) and two of 2 frames
  * (2 symbols per lane): 1, 1.5, 1.5 filter units on the three SIMDs the serial wave leaves free.
  *
- * FIR wave layout (numbers of the narrow geometry, Geom<16,4,4,1>; the wide
- * one, Geom<16,2,8,0>, halves R, S and the window, see struct Geom): lane =
- * (frame f of 4) x (q of 16); per chunk of S = 64
+ * FIR wave layout of rx_fused_pipe_kernel (Geom<16,4,4,1>; rx_pipe2_kernel further down lays the same pipeline
+ * out for 32 frames per workgroup): lane = (frame f of 4) x (q of 16); per chunk of S = 64
  * symbols the lane produces the R = 4 consecutive symbols 4q..4q+3 of its
  * frame with a sliding window: one 8-byte LDS read feeds up to 4 of the 508
  * multiply-adds, taps come from LDS broadcast reads (R + 1 groups of 8 live at
@@ -45,6 +44,7 @@
 #include <stdint.h>
 #include "qpsk_device.h"
 #include "costas_asm.h"
+#include "fir_r2_asm.h"
 #include "kernels.h"
 
 namespace qpsk {
@@ -53,7 +53,7 @@ namespace pipe {
 
 constexpr int C = 8;            /* CYCLES this instantiation is built for */
 constexpr int DR = 2;            /* depth of the symbol rings in chunks */
-constexpr int MAX_WAVES = 16;    /* ready[] counters: FIR waves of the widest geometry / two-frame units of rx_pipe2_kernel */
+constexpr int MAX_WAVES = 16;    /* ready[] counters: FIR waves of rx_fused_pipe_kernel / two-frame units of rx_pipe2_kernel */
 constexpr int SPIN_LIMIT = 1 << 24;
 
 /* Result-changing ablation knobs (FusedArgs::dbg bit 0: skip the filter arithmetic, bit 1: skip the recurrence) exist
@@ -71,10 +71,7 @@ constexpr int SPIN_LIMIT = 1 << 24;
  *                workgroup; the serial wave has a SIMD of its own (spare waves retire at once) and three SIMDs
  *                filter.  Lane mappings of its FIR waves: (frame of 4) x (q of 16) with 4 symbols per lane, or
  *                (frame of 2) x (q of 32) with 2 symbols per lane -- both in one workgroup when it is full (see
- *                the kernel).  Batches above 16 frames per CU run in rounds of such workgroups.
- *   Geom<16, 2>  "wide" (QPSK_PIPE_WIDE=1 only): chunks of 32 symbols, 32 frames and 8 FIR waves per workgroup, two of
- *                them beside the serial wave.  It was the faster choice for 8192 frames per GPU while the serial
- *                wave wrote a 16-byte record every step; with phase records the narrow rounds are (api.cpp).
+ *                the kernel).  Batches above 16 frames per CU go to rx_pipe2_kernel (api.cpp).
  */
 template <int QL_, int R_, int MAX_NF_, int SPARE_, bool PINNED_>
 struct Geom {
@@ -104,10 +101,8 @@ struct WaveMap {
     static constexpr int QL = QL_, R = R_;
 };
 using GeomNarrow = Geom<16, 4, 4, 1, true>;
-/* 8 FIR waves, two per SIMD, the serial wave the third on SIMD 0.  Measured and NOT kept: spare waves (3, 3, 2
- * FIR waves per SIMD starve the youngest: 0.394 against 0.371 ms); 7 FIR waves sharing 8 frame groups in turn
- * (no FIR wave twice on the serial wave's SIMD: 0.364 against 0.371 ms, within the run-to-run noise) */
-using GeomWide = Geom<16, 2, 8, 0, true>;
+/* (Round 1 also had a "wide" geometry, Geom<16, 2, 8, 0>: 32 frames per workgroup in 32-symbol chunks, per-frame
+ * windows, FIR waves beside the serial wave -- 0.365-0.379 ms at 8192 frames.  rx_pipe2_kernel below replaces it.) */
 
 #define QPSK_GEOM_CONSTANTS(GM)                                                                          \
     constexpr int QL = GM::QL, R = GM::R, FWV = GM::FWV, S = GM::S, CH = GM::CH, WSLOTS = GM::WSLOTS,    \
@@ -163,8 +158,8 @@ using namespace pipe;
 
 /*
  * The serial wave: one lane per (frame, loop).  It waits for chunk c of its frame in the symbol ring (counter
- * ready[]), advances the loop over the chunk's symbols and leaves one 16-byte record per symbol in the record
- * ring, then publishes consumed = c + 1.  Shared by rx_fused_pipe_kernel (ring fed by FIR waves) and
+ * ready[]), advances the loop over the chunk's symbols and leaves one 4-byte record per symbol in the record
+ * ring (the phase the step started from, four steps per write), then publishes consumed = c + 1.  Shared by rx_fused_pipe_kernel (ring fed by FIR waves) and
  * costas_pipe_kernel (ring fed from already decimated symbols in global memory).
  */
 template <class GM>
@@ -174,7 +169,12 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
     QPSK_GEOM_CONSTANTS(GM);
     const int nbw = a.nbw, N = a.nsym;
     /* =============================== Costas + slicer wave ===================================== */
-    __builtin_amdgcn_s_setprio(3);
+    /* Alone on its SIMD the wave takes priority 3.  rx_pipe2_kernel may place a FIR wave beside it (a.share_simd0):
+     * the recurrence has slack there (32 frames per workgroup: the filter is the limit) and a FIR wave that only
+     * gets the serial wave's leftovers becomes the slowest of the workgroup, so the priorities are the other way
+     * round: this wave 1, the FIR wave beside it 3 [measured: 0.335 -> 0.294 ms at 8192 frames] */
+    if (a.share_simd0 != ((a.dbg & 512) != 0)) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(3);
     const int g = lane / nbw, b = lane - g * nbw;
     const bool active = lane < G * nbw && f0 + g < a.nframes;
     Loop st = {0.0f, 0.0f};
@@ -831,20 +831,26 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
 #ifndef QPSK_PIPE2_MAXFIR
 #define QPSK_PIPE2_MAXFIR 9  /* FIR waves per workgroup: 9 = three per SIMD (at most 168 VGPRs), 6 = two per SIMD */
 #endif
+#ifndef QPSK_PIPE2_ASM
+#define QPSK_PIPE2_ASM 1     /* 1: the FIR step as the generated instruction stream fir_r2_asm.h; 0: the compiler's (A/B builds) */
+#endif
 #ifndef QPSK_PIPE2_DEPTH
-#define QPSK_PIPE2_DEPTH 2   /* blocks of 8 window positions fetched ahead of their use (measured: see DESIGN.md 4.1) */
+#define QPSK_PIPE2_DEPTH 1   /* blocks of 8 window positions fetched ahead of their use (measured: see DESIGN.md 4.1) */
 #endif
 namespace pipe2 {
 constexpr int QL = 32, R = 2, UF = 2;                    /* lanes per frame, symbols per lane, frames per unit */
 constexpr int S = GeomNarrow::S, CH = S * C;              /* 64 symbols = 512 samples per chunk per frame */
-constexpr int PAD = R * C;                                /* 16: position p lives at slot p + p/16, lanes 17 slots apart */
+constexpr int PAD = R * C, PADS = 2;                      /* position p lives at slot p + 2 (p/16): lanes 18 slots = 144 bytes apart, so a
+                                                             lane's positions (t, t+1), t even, are one aligned 16-byte word and the
+                                                             16 lanes of a ds_read_b128 pass start in 16 different bank quads */
 constexpr int TSTEPS = NTAPS + C * (R - 1);               /* 135 window positions per lane per chunk */
 constexpr int NLD = CH / 128;                             /* 16-byte loads per frame per chunk */
-constexpr int BLK = 128 + 128 / PAD;                      /* slots per 128-sample block */
-constexpr int WS = 680;                                   /* slots per frame window: positions 0..637 -> slots 0..676 */
+constexpr int BLK = 128 + PADS * (128 / PAD);             /* slots per 128-sample block */
+constexpr int WS = 720;                                   /* slots per frame window: positions 0..637 -> slots 0..715 */
+__device__ __host__ constexpr int slot_of(int p) { return p + PADS * (p / PAD); }
 constexpr int MAX_UNITS = 16, MAX_FIR = QPSK_PIPE2_MAXFIR, MAX_UW = (MAX_UNITS + MAX_FIR - 1) / MAX_FIR;   /* units per workgroup, FIR waves, units per FIR wave */
 constexpr int MAX_THREADS = 64 * (MAX_FIR + 1 + (MAX_FIR - 1) / 3);   /* 12 hardware waves */
-static_assert(S == QL * R && CH % 128 == 0 && (CH + HIST - 1) + (CH + HIST - 1) / PAD < WS &&
+static_assert(S == QL * R && CH % 128 == 0 && slot_of(CH + HIST - 1) < WS && WS % 2 == 0 && PAD % 2 == 0 &&
               PAD * (QL - 1) + TSTEPS - 1 <= CH + HIST - 1 - (C - 1), "window geometry: every position a lane reads is written for every index < C");
 static_assert(MAX_UNITS <= MAX_WAVES, "one ready[] counter per unit");
 
@@ -853,37 +859,37 @@ struct Unit {
     int u;                    /* unit number in the workgroup = its ready[] counter; frames 2u, 2u + 1 */
     bool fv[UF], all_valid;   /* frames inside the batch */
     const float4 *src[UF];
-    int wr0[UF], wr1[UF];     /* per lane: window slots of the pair this lane loads from block 0 of a chunk */
+    int ix[UF];               /* the frames' decimation offsets (< C): sample 2*lane of a chunk lives at window position
+                                 2*lane + HIST - ix; when ix is even the lane's pair is one aligned 16-byte word */
     float4 hist[UF];          /* per lane: the pair it loaded from the LAST block of the previous chunk */
 };
 } // namespace pipe2
 
 template <int NUW>
 __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *mywin, float2 *dring, float *zring, int G,
-                                          int widx, int nfir, int f0, int lane, int nchunks, int *status)
+                                          int widx, int u0, int f0, int lane, int nchunks, int *status)
 {
     using namespace pipe2;
     using GM = GeomNarrow;    /* ring geometry (S, DSTRIDE, ZSTRIDE) shared with costas_wave / flush_records */
     constexpr int DSTRIDE = GM::DSTRIDE;
     const int L = a.frame_size;
     const int fl = lane / QL, q = lane % QL;
+    const bool simd0 = ((threadIdx.x >> 6) & 3) == 0;       /* a FIR wave placed beside the serial wave (layout) */
     const float4 *taps4 = reinterpret_cast<const float4 *>(sm->taps);
-    const float2 *rd = mywin + fl * WS + (PAD + 1) * q;      /* FIR read base: position PAD*q -> slot (PAD+1)*q */
+    const float2 *rd = mywin + fl * WS + (PAD + PADS) * q;   /* FIR read base: position PAD*q -> slot (PAD+PADS)*q */
 
     Unit un[NUW];
 #pragma unroll
     for (int ui = 0; ui < NUW; ui++) {
         Unit &U = un[ui];
-        U.u = widx + ui * nfir;
+        U.u = u0 + ui;
         U.all_valid = UF * U.u + UF <= G && f0 + UF * U.u + UF <= a.nframes;
 #pragma unroll
         for (int ff = 0; ff < UF; ff++) {
             const int fr = f0 + UF * U.u + ff;
             U.fv[ff] = UF * U.u + ff < G && fr < a.nframes;      /* an odd G leaves the last unit one frame */
             const int ix = a.index ? (U.fv[ff] ? a.index[fr] : 0) : a.fixed_index;   /* decimation offset, < C */
-            const int p0 = 2 * lane + HIST - ix;                    /* window position of sample 2*lane of the chunk */
-            U.wr0[ff] = ff * WS + p0 + p0 / PAD;
-            U.wr1[ff] = ff * WS + (p0 + 1) + (p0 + 1) / PAD;
+            U.ix[ff] = __builtin_amdgcn_readfirstlane(ix);
             U.src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(U.fv[ff] ? fr : 0) * L);
             U.hist[ff] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       /* a fresh delay line (qpsk.c:37) */
         }
@@ -931,16 +937,39 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
     /* one unit of one chunk: stage the window from registers, start the next loads, filter, flush what the loop has
      * finished with, hand over */
     auto run_unit = [&](Unit &U, float4 (&pre)[UF][NLD], int c, const Unit &next, bool has_next, int cnext) -> bool {
+        /* Waves of a SIMD are served oldest first, so the older FIR waves would race two chunks ahead of the loop and
+         * then sleep while the youngest, whose chunk the loop is waiting for, crawls along alone (a lone wave pays for
+         * every LDS instruction and every dependent result itself).  Priority by need instead: the fewer chunks a
+         * wave is ahead of the loop, the higher its priority, so the waves of a SIMD advance together and keep its
+         * issue slots full.  (The serial wave runs at priority 3.) */
+        if (a.dbg & 256) {
+        } else if (simd0 && !(a.dbg & 1024)) {
+            __builtin_amdgcn_s_setprio(3);
+        } else {
+            const int lead = c - __hip_atomic_load(&sm->consumed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lead <= 0) __builtin_amdgcn_s_setprio(2);
+            else if (lead == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         /* history (the previous chunk's last block, one block below block 0: the lanes whose pair lies before
          * the first tap's reach are skipped), then this chunk's samples */
 #pragma unroll
         for (int ff = 0; ff < UF; ff++) {
-            if (U.wr0[ff] - ff * WS - BLK >= 0) mywin[U.wr0[ff] - BLK] = make_float2(U.hist[ff].x, U.hist[ff].y);
-            if (U.wr1[ff] - ff * WS - BLK >= 0) mywin[U.wr1[ff] - BLK] = make_float2(U.hist[ff].z, U.hist[ff].w);
+            const int p0 = 2 * lane + HIST - U.ix[ff];             /* window position of sample 2*lane of the chunk */
+            float2 *w0 = mywin + ff * WS + slot_of(p0), *w1 = mywin + ff * WS + slot_of(p0 + 1);
+            if ((U.ix[ff] & 1) == 0) {      /* wave-uniform: every lane holds a pair of frame ff here */
+                if (p0 >= 128) *reinterpret_cast<float4 *>(w0 - BLK) = U.hist[ff];
 #pragma unroll
-            for (int j = 0; j < NLD; j++) {
-                mywin[U.wr0[ff] + BLK * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
-                mywin[U.wr1[ff] + BLK * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
+                for (int j = 0; j < NLD; j++)
+                    *reinterpret_cast<float4 *>(w0 + BLK * j) = pre[ff][j];
+            } else {
+                if (p0 >= 128) w0[-BLK] = make_float2(U.hist[ff].x, U.hist[ff].y);
+                if (p0 + 1 >= 128) w1[-BLK] = make_float2(U.hist[ff].z, U.hist[ff].w);
+#pragma unroll
+                for (int j = 0; j < NLD; j++) {
+                    w0[BLK * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
+                    w1[BLK * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
+                }
             }
             U.hist[ff] = pre[ff][NLD - 1];
         }
@@ -950,6 +979,11 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
         /* sliding-window FIR, the pinned two-symbol step of rx_fused_pipe_kernel: symbol r of this lane uses tap
          * k = t - C*r at window position PAD*q + t; taps 0..126 in order into one accumulator per symbol */
         v2f ac[R] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
+#if QPSK_PIPE2_ASM
+        if (!QPSK_ABLATE(a, 1)) {
+            /* the hand-scheduled stream (fir_r2_asm.h, generated by tools/gen_fir_asm.py): the sum below, same order */
+            fir_r2_asm(lds_addr(rd), lds_addr(sm->taps), ac[0], ac[1]);
+#else
         if (!QPSK_ABLATE(a, 1)) {
             /* Two symbols per lane leave a lone multiply/add pair per symbol and window position: too little
              * independent work for a wave that waits 8 cycles on every dependent result.  So positions go in PAIRS:
@@ -968,9 +1002,13 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
                     g_[4] = tb4.x; g_[5] = tb4.y; g_[6] = tb4.z; g_[7] = tb4.w;
                 }
 #pragma unroll
-                for (int u = 0; u < C; u++) {
-                    const int t = tb * C + u;
-                    if (t < TSTEPS) wv[tb % NW][u] = rd[t + t / PAD];
+                for (int u = 0; u < C; u += 2) {
+                    const int t = tb * C + u;      /* t even: positions t, t + 1 are one aligned 16-byte word */
+                    if (t < TSTEPS) {
+                        const float4 w4 = *reinterpret_cast<const float4 *>(rd + slot_of(t));
+                        wv[tb % NW][u] = make_float2(w4.x, w4.y);
+                        wv[tb % NW][u + 1] = make_float2(w4.z, w4.w);
+                    }
                 }
             };
             static_for<0, DEPTH>([&](auto d) { if (decltype(d)::value < NB) fetch_block(decltype(d)::value); });
@@ -1006,6 +1044,7 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
                     }
                 });
             });
+#endif
         } else {
             ac[0] = v2f{0.7f, 0.3f}; ac[1] = v2f{0.7f, 0.3f};
         }
@@ -1061,16 +1100,15 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
 }
 
 __global__ void __launch_bounds__(pipe2::MAX_THREADS)
-rx_pipe2_kernel(FusedArgs a, int nfir, int *status)
+rx_pipe2_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
 {
     using namespace pipe2;
     using GM = GeomNarrow;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem *sm = reinterpret_cast<Smem *>(smem_raw);
-    const int G = a.G;                                   /* frames of a workgroup (even unless the batch is smaller) */
-    const int NU = (G + UF - 1) / UF;                     /* units */
-    float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));      /* [nfir][UF][WS] */
-    float2 *dring = win + (size_t)nfir * UF * WS;                            /* [G][DSTRIDE] */
+    const int G = a.G;                                   /* frames of a workgroup */
+    float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));      /* [nwin][UF][WS]: one window per FIR wave */
+    float2 *dring = win + (size_t)nwin * UF * WS;                            /* [G][DSTRIDE] */
     float *zring = reinterpret_cast<float *>(dring + (size_t)G * GM::DSTRIDE);   /* [G*nbw][ZSTRIDE] */
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1087,22 +1125,29 @@ rx_pipe2_kernel(FusedArgs a, int nfir, int *status)
         costas_wave<GM>(a, sm, dring, zring, G, f0, lane, nchunks, status);   /* a.mixed == 2: lane g waits on ready[g / 2] */
         return;
     }
-    if ((wave & 3) == 0) return;                          /* would share the serial wave's SIMD */
-    const int widx = wave - 1 - wave / 4;                 /* FIR wave index 0 .. nfir-1 */
-    if (widx >= nfir || widx >= NU) return;
+    /* layout: 4 bits per hardware wave = the units it owns (consecutive units, in wave order); 0 = the wave retires at
+     * once (the host leaves the serial wave's SIMD -- waves 4, 8 -- empty unless asked otherwise) */
+    const int mine = (int)((layout >> (4 * wave)) & 15);
+    if (mine == 0) return;
+    int u0 = 0, widx = 0;
+    for (int v = 1; v < wave; v++) {
+        const int cv = (int)((layout >> (4 * v)) & 15);
+        u0 += cv;
+        widx += cv != 0;
+    }
     float2 *mywin = win + (size_t)widx * UF * WS;
-    if (MAX_UW >= 3 && widx + 2 * nfir < NU)
-        fir_wave2<(MAX_UW >= 3 ? 3 : 1)>(a, sm, mywin, dring, zring, G, widx, nfir, f0, lane, nchunks, status);
-    else if (widx + nfir < NU)
-        fir_wave2<2>(a, sm, mywin, dring, zring, G, widx, nfir, f0, lane, nchunks, status);
+    if (MAX_UW >= 3 && mine >= 3)
+        fir_wave2<(MAX_UW >= 3 ? 3 : 1)>(a, sm, mywin, dring, zring, G, widx, u0, f0, lane, nchunks, status);
+    else if (mine == 2)
+        fir_wave2<2>(a, sm, mywin, dring, zring, G, widx, u0, f0, lane, nchunks, status);
     else
-        fir_wave2<1>(a, sm, mywin, dring, zring, G, widx, nfir, f0, lane, nchunks, status);
+        fir_wave2<1>(a, sm, mywin, dring, zring, G, widx, u0, f0, lane, nchunks, status);
 }
 
-size_t pipe2_lds_bytes(int G, int nfir, int nbw)
+size_t pipe2_lds_bytes(int G, int nwin, int nbw)
 {
     using GM = GeomNarrow;
-    size_t b = sizeof(Smem) + sizeof(float2) * ((size_t)nfir * pipe2::UF * pipe2::WS + (size_t)G * GM::DSTRIDE) +
+    size_t b = sizeof(Smem) + sizeof(float2) * ((size_t)nwin * pipe2::UF * pipe2::WS + (size_t)G * GM::DSTRIDE) +
                sizeof(float) * (size_t)G * nbw * GM::ZSTRIDE;
     return (b + 15) & ~(size_t)15;
 }
@@ -1110,21 +1155,58 @@ size_t pipe2_lds_bytes(int G, int nfir, int nbw)
 int pipe2_max_fir(void) { return pipe2::MAX_FIR; }
 int pipe2_max_frames(void) { return pipe2::UF * pipe2::MAX_UNITS; }
 int pipe2_max_units_per_wave(void) { return pipe2::MAX_UW; }
+int pipe2_max_hw_waves(void) { return pipe2::MAX_THREADS / 64; }
 
-/* G frames per workgroup (at most 32, G * nbw <= 64), nfir FIR waves (units / 2 rounded up .. 9) */
-int launch_rx_pipe2(const FusedArgs &a0, int G, int nfir, int *status, hipStream_t s)
+/*
+ * The default layout for NU units [measured, DESIGN.md 4.1].
+ *   NU <= 8 (up to 16 frames per workgroup: the recurrence is the limit): one unit per wave on hardware waves 1-3,
+ *     5-7, 9, 10 -- SIMDs 1-3; waves 4 and 8 would sit beside the serial wave and retire at once.
+ *   NU > 8 (the filter is the limit): the serial wave leaves three quarters of its SIMD's issue slots unused, so
+ *     hardware wave 4 filters too: one unit each on waves 1-7, 9, 10, then a second one on waves 1, 2, ... -- a full
+ *     workgroup's 16 units sit 2, 5, 5, 4 on SIMDs 0-3 (nine windows are what the LDS holds beside 32 frames' rings).
+ *     The kernel then runs the serial wave at priority 1 and the FIR wave beside it at 3 (see there).
+ */
+unsigned long long pipe2_default_layout(int NU)
+{
+    using namespace pipe2;
+    int cnt[16] = {0};
+    const int hwmax = MAX_THREADS / 64;
+    const bool share = NU > 8 && MAX_UW == 2;
+    int left = NU;
+    for (int round = 0; round < MAX_UW && left > 0; round++)
+        for (int w = 1; w < hwmax && left > 0; w++) {
+            if ((w & 3) == 0 && !(share && w == 4)) continue;
+            if (share && (w == 11 || (round == 1 && w > 7))) continue;
+            cnt[w]++;
+            left--;
+        }
+    unsigned long long layout = 0;
+    for (int w = 1; w < hwmax; w++) layout |= (unsigned long long)cnt[w] << (4 * w);
+    return left == 0 ? layout : 0;
+}
+
+/* G frames per workgroup (at most 32, G * nbw <= 64); layout as in the kernel: its counts must add up to the units */
+int launch_rx_pipe2(const FusedArgs &a0, int G, unsigned long long layout, int *status, hipStream_t s)
 {
     using namespace pipe2;
     FusedArgs a = a0;
     const int NU = (G + UF - 1) / UF;
-    if (G < 1 || G > UF * MAX_UNITS || G * a.nbw > 64 || nfir < 1 || nfir > MAX_FIR || nfir * MAX_UW < NU ||
-        pipe2_lds_bytes(G, nfir, a.nbw) > (size_t)MAX_LDS_BYTES)
+    int units = 0, nwin = 0, hw = 1;
+    for (int w = 1; w < 16; w++) {
+        const int cw = (int)((layout >> (4 * w)) & 15);
+        if (cw > MAX_UW || (cw && w >= MAX_THREADS / 64)) return (int)hipErrorInvalidValue;
+        units += cw;
+        nwin += cw != 0;
+        if (cw) hw = w + 1;
+    }
+    if (G < 1 || G > UF * MAX_UNITS || G * a.nbw > 64 || units != NU || (layout & 15) ||
+        pipe2_lds_bytes(G, nwin, a.nbw) > (size_t)MAX_LDS_BYTES)
         return (int)hipErrorInvalidValue;
     a.G = G;
     a.mixed = 2;                                          /* the serial wave's lane for frame g waits on ready[g / 2] */
+    a.share_simd0 = ((layout >> 16) & 15) != 0 || ((layout >> 32) & 15) != 0;   /* hardware waves 4, 8 */
     const int blocks = (a.nframes + G - 1) / G;
-    const int hw = nfir + 1 + (nfir - 1) / 3;             /* FIR wave k is hardware wave k + 1 + k/3 */
-    hipLaunchKernelGGL(rx_pipe2_kernel, dim3(blocks), dim3(64 * hw), pipe2_lds_bytes(G, nfir, a.nbw), s, a, nfir, status);
+    hipLaunchKernelGGL(rx_pipe2_kernel, dim3(blocks), dim3(64 * hw), pipe2_lds_bytes(G, nwin, a.nbw), s, a, layout, nwin, status);
     return (int)hipGetLastError();
 }
 
@@ -1143,39 +1225,35 @@ static size_t lds_bytes_of(int NF, int nbw)
     return (b + 15) & ~(size_t)15;
 }
 
-size_t pipe_lds_bytes(int NF, int nbw, bool wide)
+size_t pipe_lds_bytes(int NF, int nbw)
 {
-    return wide ? lds_bytes_of<GeomWide>(NF, nbw) : lds_bytes_of<GeomNarrow>(NF, nbw);
+    return lds_bytes_of<GeomNarrow>(NF, nbw);
 }
 
-int pipe_frames(int NF, bool wide) { return wide ? frames_of<GeomWide>(NF) : frames_of<GeomNarrow>(NF); }
+int pipe_frames(int NF) { return frames_of<GeomNarrow>(NF); }
 int pipe_cycles(void) { return C; }
-int pipe_max_nf(bool wide) { return wide ? GeomWide::MAX_NF : GeomNarrow::MAX_NF; }
+int pipe_max_nf(void) { return GeomNarrow::MAX_NF; }
 
-int launch_rx_fused_pipe(const FusedArgs &a0, int NF, bool wide, int *status, hipStream_t s)
+int launch_rx_fused_pipe(const FusedArgs &a0, int NF, int *status, hipStream_t s)
 {
     FusedArgs a = a0;
     /* the full narrow workgroup runs with two lane mappings (see the kernel): no SIMD carries two four-frame
      * units, every FIR wave has slack and the kernel follows the loop.  QPSK_PIPE_DBG bit 7 = the plain layout
      * (4 FIR waves + 1 spare) for A/B runs */
-    a.mixed = !wide && NF == GeomNarrow::MAX_NF && !(a.dbg & (128 | 4));
+    a.mixed = NF == GeomNarrow::MAX_NF && !(a.dbg & (128 | 4));
     /* several loops per frame (bandwidth sweeps): the flush costs a sin/cos per loop and symbol, so the frames go
      * two to a FIR wave (2 symbols per lane) instead of four */
-    if (!wide && !a.mixed && a.nbw > 1 && NF <= 3 && !(a.dbg & (128 | 4))) a.mixed = 2;
-    const int G = pipe_frames(NF, wide);
+    if (!a.mixed && a.nbw > 1 && NF <= 3 && !(a.dbg & (128 | 4))) a.mixed = 2;
+    const int G = pipe_frames(NF);
     const int blocks = (a.nframes + G - 1) / G;
-    const size_t lds = pipe_lds_bytes(NF, a.nbw, wide);
-    if (NF < 1 || NF > pipe_max_nf(wide) || lds > (size_t)MAX_LDS_BYTES || G * a.nbw > 64) return (int)hipErrorInvalidValue;
+    const size_t lds = pipe_lds_bytes(NF, a.nbw);
+    if (NF < 1 || NF > pipe_max_nf() || lds > (size_t)MAX_LDS_BYTES || G * a.nbw > 64) return (int)hipErrorInvalidValue;
     /* hardware waves of a workgroup with NF FIR waves: with spares, FIR wave k is hardware wave k + 1 + k/3 */
     const int nfir = a.mixed == 2 ? 2 * NF : NF;
     auto nwaves = [&](int spare) { return (spare && !(a.dbg & 4)) ? nfir + 1 + (nfir - 1) / 3 : nfir + 1; };
-    if (wide) {
-        hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomWide>, dim3(blocks), dim3(64 * nwaves(GeomWide::SPARE)), lds, s, a, status);
-    } else {
-        /* mixed: hardware waves 0 (loop), 1-3 (4 frames each), 4-5 (retire), 6-7 (2 frames each) */
-        const dim3 threads(a.mixed == 1 ? 512 : 64 * nwaves(GeomNarrow::SPARE));
-        hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrow>, dim3(blocks), threads, lds, s, a, status);
-    }
+    /* mixed: hardware waves 0 (loop), 1-3 (4 frames each), 4-5 (retire), 6-7 (2 frames each) */
+    const dim3 threads(a.mixed == 1 ? 512 : 64 * nwaves(GeomNarrow::SPARE));
+    hipLaunchKernelGGL(rx_fused_pipe_kernel<GeomNarrow>, dim3(blocks), threads, lds, s, a, status);
     hipError_t e = hipGetLastError();
     return (int)e;
 }
@@ -1194,9 +1272,6 @@ int prepare_pipe_kernel(void)
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(costas_pipe_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomWide>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_pipe2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             MAX_LDS_BYTES);

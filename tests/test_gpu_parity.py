@@ -134,36 +134,42 @@ def test_rx_batch_tilings_agree(oracle):
 @pytest.mark.parametrize("L,mode", [(2048, TIMING_FIXED), (1000, TIMING_FIXED), (2048, TIMING_HIST), (16384, TIMING_FIXED)])
 def test_pipeline_geometries_agree(oracle, L, mode):
     """every layout of the pipeline kernels gives the oracle's bits: rx_pipe2_kernel (two-frame units, 1..32 frames
-    per workgroup, 1..9 FIR waves owning one or two units each) and the two geometries of rx_fused_pipe_kernel (4 or 2
-    symbols per FIR lane, up to 16 or 32 frames per workgroup); frame counts are ragged against all of them"""
+    per workgroup, 1..9 FIR waves owning one or two units each) and the lane mappings of rx_fused_pipe_kernel (4 or 2
+    symbols per FIR lane in one 16-frame workgroup); frame counts are ragged against all of them"""
     fs, rs, F = 19200.0, 2400.0, 75
     m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=mode, fixed_index=5)
     x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=L, noise=0.05)
     x[7] = 0.0
     want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=mode, fixed_index=5, want_costas=True)
     m.tune(pipe_v=2)
-    for G, nf in ((None, None), (1, 1), (2, 1), (3, 1), (3, 2), (5, 3), (16, 8), (16, 4), (17, 9), (18, 5), (31, 8), (32, 9), (32, 8)):
-        m.tune(pipe_g=G, pipe_nf=nf)
+    # frames per workgroup (two-frame units dealt to up to nine FIR waves by the library) ...
+    for G in (None, 1, 2, 3, 5, 16, 17, 18, 31, 32):
+        m.tune(pipe_g=G)
         got = m.rx_batch(x, want_costas=True)
         m.sync()
         assert_batch_equal(got, want)
         got = m.rx_batch(x[:33], want_costas=False)
         m.sync()
         assert bits_equal(cpu(got["sym"]), want["sym"][:33]) and bits_equal(cpu(got["freq"]), want["freq"][:33])
+    # ... and explicit wave layouts (4 bits per hardware wave = units it owns, waves 1-5 / 6-11): one wave with two
+    # units; a FIR wave beside the serial wave (hardware wave 4); 32 frames on nine waves with SIMD 0 carrying two units
+    for G, lo, hi in ((4, 0x00002, 0), (6, 0x01011, 0), (10, 0x11111, 0), (32, 0x22222, 0x011022), (32, 0x20222, 0x112022), (24, 0x20222, 0x000022)):
+        m.tune(pipe_g=G, pipe_layout_lo=lo, pipe_layout_hi=hi)
+        got = m.rx_batch(x, want_costas=True)
+        m.sync()
+        assert_batch_equal(got, want)
+    m.tune(pipe_layout_lo=None, pipe_layout_hi=None)
     m.tune(pipe_v=1, pipe_g=None, pipe_nf=None)
-    for wide, nfs in ((0, (1, 2, 3, 4)), (1, (1, 3, 5, 8))):
-        for nf in nfs:
-            m.tune(pipe_wide=wide)
-            m.tune(pipe_nf=nf)
-            got = m.rx_batch(x, want_costas=True)
-            m.sync()
-            assert_batch_equal(got, want)
-            got = m.rx_batch(x[:33], want_costas=False)
-            m.sync()
-            assert bits_equal(cpu(got["sym"]), want["sym"][:33]) and bits_equal(cpu(got["freq"]), want["freq"][:33])
+    for nf in (1, 2, 3, 4):
+        m.tune(pipe_nf=nf)
+        got = m.rx_batch(x, want_costas=True)
+        m.sync()
+        assert_batch_equal(got, want)
+        got = m.rx_batch(x[:33], want_costas=False)
+        m.sync()
+        assert bits_equal(cpu(got["sym"]), want["sym"][:33]) and bits_equal(cpu(got["freq"]), want["freq"][:33])
     # nf = 4 above ran with two lane mappings in one workgroup (16 frames: 12 at 4 symbols per lane, 4 at 2);
     # the A/B variant with one mapping for all four FIR waves
-    m.tune(pipe_wide=0)
     m.tune(pipe_nf=4)
     m.tune(pipe_dbg=128)
     got = m.rx_batch(x, want_costas=True)
@@ -270,7 +276,7 @@ def test_full_size_config4_shard_properties(oracle):
                            fixed_index=bench.FIXED_INDEX)
     for k in ("sym", "phase", "freq", "hz"):
         assert bits_equal(cpu(a[k])[pick], want[k]), k
-    m.tune(pipe_v=1, pipe_wide=0)
+    m.tune(pipe_v=1)
     b = m.rx_batch(x)
     m.sync()
     for k in ("sym", "phase", "freq"):
@@ -288,8 +294,8 @@ def test_smallest_frames(oracle, mode):
         for F in (1, 3):
             x = random_frames(F, L, seed=L + F, scale=0.7)
             want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=mode, fixed_index=7, want_costas=True)
-            for v, wide in ((2, 0), (1, 0), (1, 1)):
-                m.tune(pipe_v=v, pipe_wide=wide)
+            for v in (2, 1):
+                m.tune(pipe_v=v)
                 got = m.rx_batch(x, want_costas=True)
                 m.sync()
                 assert_batch_equal(got, want)
@@ -321,9 +327,9 @@ def test_randomised_configurations(oracle):
         want = oracle.rx_batch(x, fs, rs, loop_bw=bw, min_freq=lo, max_freq=hi, timing_mode=mode, fixed_index=idx,
                                want_costas=True)
         if case % 3 == 0:     # a third of the cases through rx_fused_pipe_kernel's two geometries
-            m.tune(pipe_v=1, pipe_wide=case % 2, pipe_nf=1 + case % 8)
+            m.tune(pipe_v=1, pipe_nf=1 + case % 4)
         else:
-            m.tune(pipe_v=2, pipe_g=1 + (case * 7) % 32, pipe_nf=1 + case % 9)
+            m.tune(pipe_v=2, pipe_g=1 + (case * 7) % 32)
         got = m.rx_batch(x, want_costas=True)
         m.sync()
         try:
@@ -333,18 +339,26 @@ def test_randomised_configurations(oracle):
                 case, L, F, scale, bw, lo, hi, mode, idx, e))
 
 
-def test_two_loops_per_frame_in_the_wide_geometry(oracle):
-    """several loops per frame in the 32-symbol-chunk geometry (the host sheds FIR waves until the record rings
-    of all loops fit the LDS)"""
+def test_two_loops_per_frame_in_both_pipeline_kernels(oracle):
+    """several loops per frame (bandwidth sweeps, config 5): one lane of the serial wave and one record ring per
+    (frame, loop); the host sheds frames per workgroup until the rings fit the LDS"""
     fs, rs, L, F = 19200.0, 2400.0, 2048, 45
     bws = [np.float32(TAU / 100.0), np.float32(TAU / 170.0)]
     m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=3)
     x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=20.0, base_seed=77, noise=0.05)
     want = oracle.rx_batch_bw(x, fs, rs, bws, timing_mode=TIMING_FIXED, fixed_index=3)
-    m.tune(pipe_v=1, pipe_wide=1)
-    got = m.rx_batch_bw(x, bws)
-    m.sync()
-    assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
+    for v, g in ((1, None), (2, None), (2, 32), (2, 7)):
+        m.tune(pipe_v=v, pipe_g=g)
+        got = m.rx_batch_bw(x, bws)
+        m.sync()
+        assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
+    bws11 = [np.float32(TAU / (100.0 + 10.0 * i)) for i in range(11)]       # config 5's sweep TAU/100 .. TAU/200
+    want = oracle.rx_batch_bw(x, fs, rs, bws11, timing_mode=TIMING_FIXED, fixed_index=3)
+    for v in (1, 2):
+        m.tune(pipe_v=v, pipe_g=None)
+        got = m.rx_batch_bw(x, bws11)
+        m.sync()
+        assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
 
 
 def test_empty_and_bad_calls_are_rejected():

@@ -29,9 +29,14 @@ for frames in (4096, 8192):
     fr = torch.empty((frames,), dtype=torch.float32, device=dev)
     ph = torch.empty_like(fr)
     for st in settings:
-        m.tune(**{k: int(v) for k, v in st.items()})
-        for _ in range(3):
-            m.rx_batch_raw(x, frames, sym, fr, ph)
+        m.tune(pipe_layout_lo=None, pipe_layout_hi=None)
+        m.tune(**{k: int(v, 0) for k, v in st.items()})
+        try:
+            for _ in range(3):
+                m.rx_batch_raw(x, frames, sym, fr, ph)
+        except qpsk_amd.QpskError as e:      # a layout made for another batch size
+            print("==== %d frames, %s: skipped (%s)" % (frames, st, e), flush=True)
+            continue
         torch.cuda.synchronize()
         m.tune(pipe_dbg=32)
         print("==== %d frames, %s" % (frames, st), flush=True)

@@ -42,7 +42,7 @@ def main():
             os.environ.pop(k, None)
         for kv in c.split():
             k, v = kv.split("=")
-            os.environ[k] = v
+            os.environ[k] = str(int(v, 0))      # the library reads decimal integers
         modems[c] = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=mode, fixed_index=bench.FIXED_INDEX)
     for k in keys:
         os.environ.pop(k, None)
