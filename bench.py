@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=2048,
                     help="frames of the CPU baseline sample (0 = skip); 2048 = half a batch, ~12 s of the reference on one core")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--settle", type=float, default=0.25, help="seconds of untimed launches before the warmup steps (GPU clocks)")
     ap.add_argument("--frame-size", type=int, default=L, help="complex samples per frame (config 2: 16384)")
     args = ap.parse_args()
     L = args.frame_size
@@ -202,6 +203,14 @@ def main():
         if dist:
             dist.barrier()
 
+    # clock settle, before the W warmup steps and outside every count: a step is 0.2-0.3 ms, so W + K = 25 steps are
+    # over in 5 ms, before the GPU has left its idle clocks (the same 20 steps read 6-8 % longer cold than after
+    # 0.1 s of work).  The timed region below is still exactly K steps after exactly W warmup steps.
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        for _ in range(10):
+            m.rx_batch_raw(x, F, sym, freq, phase)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         m.rx_batch_raw(x, F, sym, freq, phase)
     torch.cuda.synchronize()
@@ -244,23 +253,25 @@ def main():
     achieved = BYTES_PER_SAMPLE * F * L / (kernel_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath):   # PMC bytes per launch of this shape's kernel (tools/collect_profiles.py), if it was profiled
         try:
             tj = json.load(open(tpath))
+            tj = tj.get("shapes", {}).get("%dx%d" % (F, L), tj)
             if tj.get("frames") == F and tj.get("frame_size") == L:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    kernel_name = "rx_pipe2_kernel" if F > 16 * torch.cuda.get_device_properties(dev).multi_processor_count else "rx_fused_pipe_kernel"
     res = {
         "metric": "complex Msamples/s demodulated + % HBM roofline, 2400-baud RRC+Costas path",
         "value": value, "unit": "Msamples/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "clock_settle_s": args.settle,
         "config": {"workload": "batch %d frames x %d complex samples per GPU, 2400 baud, 8x oversample, fused RRC FIR + Costas + slicer, fixed timing offset %d (%s)" % (
                        F, L, FIXED_INDEX, "BASELINE configs[1]" if (F, L) == (4096, 16384) else
                        "BASELINE configs[3] per-GPU share" if (F, L) == (8192, 16384) else "non-BASELINE shape"),
                    "frames_per_gpu": F, "frames_total": world * F, "gpus_visible_per_rank_box": ndev, "frame_size": L, "fs": FS, "rs": RS, "loop_bw": "TAU/100", "sharding": "independent frames per GPU, no collective"},
-        "roofline": {"bound": "hbm", "kernel": "rx_fused_pipe_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
                      "kernel_ms_event_pair_per_launch": kernel_ms_pairs,
                      "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * F * L},

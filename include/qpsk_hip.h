@@ -148,14 +148,26 @@ int qpsk_rrc_fir_batch(qpsk_ctx *ctx, float *d_memory, const float *d_in, float 
  * receives hist_i[k] + hist_q[k], k = 0..7 (qpsk.c:175, locals of rx_frame) as [nframes][8] */
 int qpsk_timing_hist_batch(qpsk_ctx *ctx, const float *d_filtered, int nframes, int32_t *d_index, int32_t *d_hist);
 
+/* The FFT timing estimate alone (QPSK_TIMING_FFT; NEW DESIGN, the reference never calls fft.c: SURVEY section 0).
+ *   d_index     [nframes] int32
+ *   d_filtered  [nframes][512] complex float, may be NULL: the 512 rrc_fir() outputs (samples 128..639 of the frame,
+ *               fresh delay line) the estimator looks at -- bit for bit what qpsk_rrc_fir_batch() returns there
+ *   d_spectrum  [nframes][512] complex double, may be NULL: fftn(|y|^2, 512) as fft.c:110-120 returns it -- bit for
+ *               bit qpsk_fft_batch() of the same 512 values
+ * so that everything below the final argmax rule is reference-pinned code (rrc_fir.c:17-30, fft.c:98-120). */
+int qpsk_timing_fft_batch(qpsk_ctx *ctx, const float *d_in, int nframes, int32_t *d_index, float *d_filtered,
+                          double *d_spectrum);
+
 /* Costas loop + slicer (qpsk.c:196-212) over already decimated symbols.
  *   d_symbols_in [nframes][nsym] complex float;  d_state [nframes][2] float (phase, freq) in/out,
  *   NULL = start from (0,0) and do not write back. */
 int qpsk_costas_batch(qpsk_ctx *ctx, const float *d_symbols_in, int nframes, int nsym, float *d_state,
                       uint8_t *d_sym, float *d_costas);
 
-/* fftn()/ifftn() (fft.c:110-136) on nbatch independent length-n transforms, n a power of two.
- *   d_in, d_out [nbatch][n] complex double; forward is scaled by 1/n, inverse is not (fft.c:105-107). */
+/* fftn()/ifftn() (fft.c:110-136) on nbatch independent length-n transforms, n a power of two up to 2^21 (one
+ * workgroup per transform in LDS up to 8192 points, two passes over global memory above).
+ *   d_in, d_out [nbatch][n] complex double, may be the same array; forward is scaled by 1/n, inverse is not
+ *   (fft.c:105-107). */
 int qpsk_fft_batch(qpsk_ctx *ctx, const double *d_in, double *d_out, int nbatch, int n, int inverse);
 
 /* -------------------------------------------------------------------------
@@ -176,6 +188,13 @@ int qpsk_streams_rx_cplx(qpsk_ctx *ctx, const float *d_in, uint8_t *d_sym, float
 /* int16 PCM input, mixed to complex on the GPU (qpsk.c:114-120) */
 int qpsk_streams_rx_pcm(qpsk_ctx *ctx, const int16_t *d_pcm, uint8_t *d_sym, float *d_freq, float *d_phase,
                         float *d_costas, int32_t *d_index);
+/* The same with HOST buffers on both sides -- the reference's call pattern (qpsk.c:344-354: fread a block, rx_frame()):
+ * one pinned copy up (PCM + loop state), the kernels, one copy down (symbols, costas_frame[], loop state, index), ONE
+ * synchronisation.  h_pcm [nstreams][frame_size]; h_loop_io [nstreams][2] (phase, freq), read before and written
+ * after the block, NULL = the carried state; h_sym [nstreams][nsym]; h_costas [nstreams][nsym][2] or NULL;
+ * h_index [nstreams] or NULL.  This is what the drop-in rx_frame() runs on. */
+int qpsk_streams_rx_pcm_host(qpsk_ctx *ctx, const int16_t *h_pcm, float *h_loop_io, uint8_t *h_sym, float *h_costas,
+                             int32_t *h_index);
 
 /* -------------------------------------------------------------------------
  * TRANSMITTERS: nstreams independent modulators advancing

@@ -110,6 +110,10 @@ struct qpsk_ctx {
     /* streams */
     int nstreams = 0;
     float *s_memory = nullptr, *s_dec = nullptr, *s_loop = nullptr, *s_mixer = nullptr;
+    /* host-pointer streaming call (qpsk_streams_rx_pcm_host: what the drop-in rx_frame() uses): pinned staging on the
+     * host, matching arena on the device; sized for nstreams blocks */
+    unsigned char *h_stage = nullptr, *d_stage = nullptr;
+    size_t stage_cap = 0;
     /* transmitters (N2) */
     int ntx = 0;
     uint8_t *t_hist = nullptr;    /* [ntx][tx_history_symbols()]: the symbols still inside tx_filter */
@@ -268,6 +272,10 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
 
 static void free_streams(qpsk_ctx *c)
 {
+    if (c->h_stage) hipHostFree(c->h_stage);
+    hipFree(c->d_stage);
+    c->h_stage = c->d_stage = nullptr;
+    c->stage_cap = 0;
     hipFree(c->s_memory); hipFree(c->s_dec); hipFree(c->s_loop); hipFree(c->s_mixer);
     c->s_memory = c->s_dec = c->s_loop = c->s_mixer = nullptr;
     c->nstreams = 0;
@@ -358,7 +366,11 @@ int qpsk_ctx_set_loop(qpsk_ctx *c, float alpha, float beta, float min_freq, floa
 {
     if (!c) return fail(QPSK_ERR_ARG, "null argument");
     if (bind(c)) return QPSK_ERR_HIP;
-    c->alpha = alpha; c->beta = beta; c->min_freq = min_freq; c->max_freq = max_freq;
+    /* the limits are kernel arguments; the gains live in device memory and go up only when they change (the
+     * drop-in rx_frame() calls this before every block) */
+    c->min_freq = min_freq; c->max_freq = max_freq;
+    if (alpha == c->alpha && beta == c->beta && !(alpha == 0.0f && beta == 0.0f)) return QPSK_OK;
+    c->alpha = alpha; c->beta = beta;
     return upload_config(c);
 }
 
@@ -401,7 +413,8 @@ static int get_twiddles(qpsk_ctx *c, int n, double **out)
     return QPSK_OK;
 }
 
-static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index)
+static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index, float *d_y = nullptr,
+                              double *d_X = nullptr)
 {
     const int C = c->cycles, nfft = timing_fft_nfft();
     if (C < 2 || C > 8 || (C & (C - 1)))
@@ -423,7 +436,7 @@ static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32
     } else {
         cs = it->second;
     }
-    KERNEL_TRY(launch_timing_fft(d_in, nframes, c->prm.frame_size, C, c->d_taps, tw, cs, d_index, c->stream));
+    KERNEL_TRY(launch_timing_fft(d_in, nframes, c->prm.frame_size, C, c->d_taps, tw, cs, d_index, d_y, d_X, c->stream));
     return QPSK_OK;
 }
 
@@ -651,6 +664,14 @@ int qpsk_timing_hist_batch(qpsk_ctx *c, const float *d_filtered, int nframes, in
     return QPSK_OK;
 }
 
+int qpsk_timing_fft_batch(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index, float *d_filtered, double *d_spectrum)
+{
+    if (!c || !d_in || !d_index) return fail(QPSK_ERR_ARG, "qpsk_timing_fft_batch: null argument");
+    if (nframes <= 0) return fail(QPSK_ERR_ARG, "nframes = %d", nframes);
+    if (bind(c)) return QPSK_ERR_HIP;
+    return fft_timing_indices(c, d_in, nframes, d_index, d_filtered, d_spectrum);
+}
+
 int qpsk_costas_batch(qpsk_ctx *c, const float *d_symbols_in, int nframes, int nsym, float *d_state, uint8_t *d_sym,
                       float *d_costas)
 {
@@ -666,13 +687,29 @@ int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, i
 {
     if (!c || !d_in || !d_out) return fail(QPSK_ERR_ARG, "qpsk_fft_batch: null argument");
     if (nbatch <= 0 || n < 1 || (n & (n - 1))) return fail(QPSK_ERR_ARG, "n = %d must be a power of two, nbatch %d > 0", n, nbatch);
-    if ((size_t)n * 16 > (size_t)MAX_LDS_BYTES) return fail(QPSK_ERR_ARG, "n = %d does not fit one workgroup's LDS (max %d)", n, MAX_LDS_BYTES / 16);
+    if (n > (1 << 21)) return fail(QPSK_ERR_ARG, "n = %d: transforms above 2^21 points are not supported (the late stages' tile must fit the LDS)", n);
     if (bind(c)) return QPSK_ERR_HIP;
     int log2n = 0;
     while ((1 << log2n) < n) log2n++;
-    double *tw = nullptr;
-    if (int rt = get_twiddles(c, n, &tw)) return rt;
-    KERNEL_TRY(launch_fft(d_in, d_out, tw, nbatch, n, log2n, inverse ? 1 : 0, c->stream));
+    if (n <= fft_lds_max_n()) {   /* one workgroup per transform, LDS-resident */
+        double *tw = nullptr;
+        if (int rt = get_twiddles(c, n, &tw)) return rt;
+        KERNEL_TRY(launch_fft(d_in, d_out, tw, nbatch, n, log2n, inverse ? 1 : 0, c->stream));
+        return QPSK_OK;
+    }
+    /* two passes over global memory (kernels.hip, fft_big_*); the first gathers bit-reversed, so it cannot run in place */
+    double *twb = nullptr, *twn = nullptr;
+    if (int rt = get_twiddles(c, fft_big_block(), &twb)) return rt;
+    if (int rt = get_twiddles(c, n, &twn)) return rt;
+    const double *src = d_in;
+    if (d_in == d_out) {
+        const size_t bytes = sizeof(double) * 2 * (size_t)nbatch * n;
+        int rc = ensure(c, c->mixed, bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->mixed.p, d_in, bytes, hipMemcpyDeviceToDevice, c->stream));
+        src = (const double *)c->mixed.p;
+    }
+    KERNEL_TRY(launch_fft_big(src, d_out, twb, twn, nbatch, n, log2n, inverse ? 1 : 0, c->stream));
     return QPSK_OK;
 }
 
@@ -774,6 +811,67 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
     /* qpsk.c:114-120 */
     KERNEL_TRY(launch_mixer(d_pcm, (float *)c->mixed.p, c->s_mixer, n, L, c->stream));
     return qpsk_streams_rx_cplx(c, (const float *)c->mixed.p, d_sym, d_freq, d_phase, d_costas, d_index);
+}
+
+/*
+ * One block per stream with HOST buffers on both sides -- the call pattern of the reference's main loop
+ * (qpsk.c:344-354: fread 512 int16, rx_frame()).  Everything a block needs goes up in ONE pinned copy (PCM, the
+ * streams' loop state, the loop gains when they changed), everything it produces comes down in ONE (symbols,
+ * costas_frame[], loop state, timing index), and the stream is synchronised ONCE, at the end; the per-call pieces
+ * qpsk_dev_upload / qpsk_streams_rx_pcm / qpsk_streams_get_loop_state / qpsk_dev_download synchronise eight times
+ * for the same work.
+ *   h_pcm [nstreams][frame_size] int16          h_loop_io [nstreams][2] (phase, freq) in and out, may be NULL (carried state)
+ *   h_sym [nstreams][nsym] uint8                h_costas [nstreams][nsym][2] float, may be NULL
+ *   h_index [nstreams] int32, may be NULL
+ */
+int qpsk_streams_rx_pcm_host(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io, uint8_t *h_sym, float *h_costas, int32_t *h_index)
+{
+    if (!c || !h_pcm || !h_sym) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_pcm_host: null argument");
+    if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
+    if (bind(c)) return QPSK_ERR_HIP;
+    const size_t n = (size_t)c->nstreams, L = (size_t)c->prm.frame_size, N = (size_t)c->nsym;
+    /* arena layout, every part 16-byte aligned: in = [loop 8n | pcm 2nL], out = [sym nN | costas 8nN | loop 8n | index 4n] */
+    auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t o_loop = 0, o_pcm = al(8 * n), in_bytes = o_pcm + al(2 * n * L);
+    const size_t o_sym = in_bytes, o_cos = o_sym + al(n * N), o_lout = o_cos + al(8 * n * N), o_idx = o_lout + al(8 * n),
+                 total = o_idx + al(4 * n);
+    if (c->stage_cap < total) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->h_stage) hipHostFree(c->h_stage);
+        hipFree(c->d_stage);
+        c->h_stage = c->d_stage = nullptr;
+        c->stage_cap = 0;
+        if (hipHostMalloc((void **)&c->h_stage, total, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&c->d_stage, total) != hipSuccess)
+            return fail(QPSK_ERR_ALLOC, "staging buffers of %zu bytes", total);
+        c->stage_cap = total;
+    }
+    if (h_loop_io) memcpy(c->h_stage + o_loop, h_loop_io, 8 * n);
+    memcpy(c->h_stage + o_pcm, h_pcm, 2 * n * L);
+    const size_t up0 = h_loop_io ? o_loop : o_pcm;
+    HIP_TRY(hipMemcpyAsync(c->d_stage + up0, c->h_stage + up0, in_bytes - up0, hipMemcpyHostToDevice, c->stream));
+    if (h_loop_io) HIP_TRY(hipMemcpyAsync(c->s_loop, c->d_stage + o_loop, 8 * n, hipMemcpyDeviceToDevice, c->stream));
+    uint8_t *d_sym = c->d_stage + o_sym;
+    float *d_cos = h_costas ? (float *)(c->d_stage + o_cos) : nullptr;
+    int32_t *d_idx = (int32_t *)(c->d_stage + o_idx);
+    int rc = qpsk_streams_rx_pcm(c, (const int16_t *)(c->d_stage + o_pcm), d_sym, nullptr, nullptr, d_cos, d_idx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_stage + o_lout, c->s_loop, 8 * n, hipMemcpyDeviceToDevice, c->stream));
+    /* one copy down: from the symbols to the index (costas_frame[] in between travels even when it is not wanted
+     * only if it was computed: without it the two parts around it go separately) */
+    if (h_costas) {
+        HIP_TRY(hipMemcpyAsync(c->h_stage + o_sym, c->d_stage + o_sym, total - o_sym, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->h_stage + o_sym, c->d_stage + o_sym, al(n * N), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_stage + o_lout, c->d_stage + o_lout, total - o_lout, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int st = check_status(c)) return st;
+    memcpy(h_sym, c->h_stage + o_sym, n * N);
+    if (h_costas) memcpy(h_costas, c->h_stage + o_cos, 8 * n * N);
+    if (h_loop_io) memcpy(h_loop_io, c->h_stage + o_lout, 8 * n);
+    if (h_index) memcpy(h_index, c->h_stage + o_idx, 4 * n);
+    return QPSK_OK;
 }
 
 /* ------------------------------------------------------------ transmit side (N2) */

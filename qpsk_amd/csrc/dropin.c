@@ -234,28 +234,20 @@ void rx_frame(int16_t in[])
     const int L = S.prm.frame_size, N = qpsk_ctx_nsym(S.ctx);
     if (!S.streams_ready) {
         MUST(qpsk_streams_reset(S.ctx, 1, S.center_hz)); /* qpsk.c:341-342 */
-        MUST(qpsk_dev_alloc(S.ctx, &S.d_pcm, sizeof(int16_t) * (size_t)L));
-        MUST(qpsk_dev_alloc(S.ctx, &S.d_sym, (size_t)N));
-        MUST(qpsk_dev_alloc(S.ctx, &S.d_costas, sizeof(complex float) * (size_t)N));
-        MUST(qpsk_dev_alloc(S.ctx, &S.d_index, sizeof(int32_t)));
         S.costas_frame = calloc((size_t)N, sizeof(complex float));
         S.symbols = calloc((size_t)N, 1);
         S.streams_ready = 1;
     }
-    const float st_in[2] = {S.phase, S.freq};
-    float st_out[2];
+    (void)L;
+    /* the loop's control surface (costas_loop.h setters) may have changed gains, limits or state since the last
+     * block: limits are kernel arguments, gains go up only when they changed, the state travels with the block.
+     * One upload, one download, one synchronisation per block (qpsk_streams_rx_pcm_host). */
+    float st[2] = {S.phase, S.freq};
     int32_t idx = 0;
     MUST(qpsk_ctx_set_loop(S.ctx, S.alpha, S.beta, S.min_freq, S.max_freq));
-    MUST(qpsk_streams_set_loop_state(S.ctx, st_in));
-    MUST(qpsk_dev_upload(S.ctx, S.d_pcm, in, sizeof(int16_t) * (size_t)L));
-    MUST(qpsk_streams_rx_pcm(S.ctx, (const int16_t *)S.d_pcm, (uint8_t *)S.d_sym, NULL, NULL, (float *)S.d_costas,
-                             (int32_t *)S.d_index));
-    MUST(qpsk_streams_get_loop_state(S.ctx, st_out));
-    MUST(qpsk_dev_download(S.ctx, S.symbols, S.d_sym, (size_t)N));
-    MUST(qpsk_dev_download(S.ctx, S.costas_frame, S.d_costas, sizeof(complex float) * (size_t)N));
-    MUST(qpsk_dev_download(S.ctx, &idx, S.d_index, sizeof idx));
-    S.phase = st_out[0];
-    S.freq = st_out[1];
+    MUST(qpsk_streams_rx_pcm_host(S.ctx, in, st, S.symbols, (float *)S.costas_frame, &idx));
+    S.phase = st[0];
+    S.freq = st[1];
     S.index = idx;
     S.offset_freq = (float)((double)S.freq * S.prm.rs / TAU_D); /* qpsk.c:217 */
 }

@@ -84,10 +84,15 @@ int launch_decimate(const float *filtered, const int32_t *index, float *dec, int
                     int cycles, int nsym, hipStream_t s);
 int launch_mixer(const int16_t *pcm, float *out, float *state, int nstreams, int frame_size, hipStream_t s);
 int launch_fft(const double *in, double *out, const double *tw, int nbatch, int n, int log2n, int inverse,
-               hipStream_t s);
+               hipStream_t s);                 /* n <= fft_lds_max_n(): one workgroup per transform, LDS-resident */
+int fft_lds_max_n(void);
+int fft_big_block(void);
+int launch_fft_big(const double *in, double *out, const double *twb, const double *twn, int nbatch, int n, int log2n,
+                   int inverse, hipStream_t s);   /* larger powers of two, two passes; in != out */
 /* timing_fft.hip */
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
-                      const double *cs, int32_t *index, hipStream_t s);
+                      const double *cs, int32_t *index, float *yout, double *Xout, hipStream_t s);   /* yout [nframes][512][2],
+                      Xout [nframes][512][2] optional: the estimator's filtered samples and spectrum, for the parity tests */
 int timing_fft_nfft(void);
 int timing_fft_first(void);
 /* bitstages.hip */

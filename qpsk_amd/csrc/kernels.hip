@@ -714,10 +714,20 @@ int launch_rx_fused(const FusedArgs &a, hipStream_t s)
     return 0;
 }
 
+__global__ void fft_big_first_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, const double2 *__restrict__ twb,
+                                     int n, int log2n, int inverse);
+__global__ void fft_big_late_kernel(double2 *__restrict__ data, const double2 *__restrict__ twn, int n, int log2n, int inverse);
+
 int prepare_kernels(void)
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_big_first_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_big_late_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(fft_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
@@ -783,6 +793,98 @@ int launch_mixer(const int16_t *pcm, float *out, float *state, int nstreams, int
 {
     hipLaunchKernelGGL(mixer_kernel, dim3((nstreams + MX_STREAMS - 1) / MX_STREAMS), dim3(64), 0, s, pcm,
                        reinterpret_cast<float2 *>(out), state, nstreams, frame_size);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+/* ========================================================================
+ * fftn / ifftn beyond what one workgroup's LDS holds (n > 8192, up to the frame lengths of the BASELINE configs:
+ * 16384 and 2^20; fft.c:110-136 take any power of two).  The same butterflies in the same order as fft_kernel --
+ * the reference's recursion is a bit-reversal followed by log2(n) stages, and WHICH workgroup performs a
+ * butterfly does not change its operands -- in two passes over global memory:
+ *   fft_big_first_kernel  block b gathers the FFTB = 4096 bit-reversed inputs that make up outputs
+ *                         [b*FFTB, (b+1)*FFTB) and runs stages 1..12 in LDS (fft_lds_stages, size-4096 table: a
+ *                         stage's angle TAU k/m does not depend on the transform it is part of);
+ *   fft_big_late_kernel   stages 13..log2(n) pair elements FFTB*2^j apart: a workgroup takes a tile of 16
+ *                         adjacent columns x n/FFTB rows (rows FFTB apart), runs the remaining stages on it in
+ *                         LDS with the size-n table (entry m*(n/size), bit-identical to the stage's own angle:
+ *                         scaling an angle's argument by a power of two is exact) and stores with the forward
+ *                         transform's division by n (fft.c:117-119).
+ * ======================================================================== */
+constexpr int FFTB_LOG2 = 12, FFTB = 1 << FFTB_LOG2, FFTB_COLS = 16, FFTB_THREADS = 256;
+
+__global__ void __launch_bounds__(FFTB_THREADS)
+fft_big_first_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, const double2 *__restrict__ twb, int n,
+                     int log2n, int inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *v = reinterpret_cast<double2 *>(smem);
+    const int tid = threadIdx.x;
+    const double2 *src = in + (size_t)blockIdx.y * n;
+    double2 *dst = out + (size_t)blockIdx.y * n;
+    const int base = blockIdx.x * FFTB;
+    for (int i = tid; i < FFTB; i += FFTB_THREADS)
+        v[i] = src[__brev((unsigned)(base + i)) >> (32 - log2n)];
+    __syncthreads();
+    fft_lds_stages(v, twb, FFTB, FFTB_LOG2, tid, FFTB_THREADS, inverse ? 1.0 : -1.0);
+    for (int i = tid; i < FFTB; i += FFTB_THREADS)
+        dst[base + i] = v[i];
+}
+
+__global__ void __launch_bounds__(FFTB_THREADS)
+fft_big_late_kernel(double2 *__restrict__ data, const double2 *__restrict__ twn, int n, int log2n, int inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double2 *t = reinterpret_cast<double2 *>(smem);           /* [rows][FFTB_COLS] */
+    const int tid = threadIdx.x;
+    const int rows = n >> FFTB_LOG2, lrows = log2n - FFTB_LOG2;
+    const int c0 = blockIdx.x * FFTB_COLS;
+    double2 *d = data + (size_t)blockIdx.y * n;
+    for (int e = tid; e < rows * FFTB_COLS; e += FFTB_THREADS)
+        t[e] = d[(size_t)(e / FFTB_COLS) * FFTB + c0 + (e % FFTB_COLS)];
+    __syncthreads();
+    const double sgn = inverse ? 1.0 : -1.0;
+    for (int st = 1; st <= lrows; st++) {
+        const int h = 1 << (st - 1);
+        const int stride = n >> (FFTB_LOG2 + st);             /* n / (stage size), stage size = 2h * FFTB */
+        for (int b = tid; b < (rows / 2) * FFTB_COLS; b += FFTB_THREADS) {
+            const int rr = b / FFTB_COLS, c = b % FFTB_COLS;
+            const int kr = rr & (h - 1);
+            const int lo = (((rr >> (st - 1)) << st) + kr) * FFTB_COLS + c, hi = lo + h * FFTB_COLS;
+            const double2 w = twn[(size_t)(kr * FFTB + c0 + c) * stride];   /* k = position inside the stage's first half */
+            const double wr = w.x, wi = sgn * w.y;
+            const double2 e = t[lo], o = t[hi];
+            const double zr = wr * o.x - wi * o.y;
+            const double zi = wr * o.y + wi * o.x;
+            t[lo] = make_double2(e.x + zr, e.y + zi);
+            t[hi] = make_double2(e.x - zr, e.y - zi);
+        }
+        __syncthreads();
+    }
+    const double dn = (double)n;
+    for (int e = tid; e < rows * FFTB_COLS; e += FFTB_THREADS) {
+        double2 r = t[e];
+        if (!inverse) { r.x = r.x / dn; r.y = r.y / dn; }    /* fft.c:117-119 */
+        d[(size_t)(e / FFTB_COLS) * FFTB + c0 + (e % FFTB_COLS)] = r;
+    }
+}
+
+int fft_lds_max_n(void) { return 8192; }
+int fft_big_block(void) { return FFTB; }
+
+/* n > fft_lds_max_n(): twb = size-FFTB table, twn = size-n table; in != out */
+int launch_fft_big(const double *in, double *out, const double *twb, const double *twn, int nbatch, int n, int log2n,
+                   int inverse, hipStream_t s)
+{
+    const int rows = n >> FFTB_LOG2;
+    if (n <= FFTB || rows * FFTB_COLS * (int)sizeof(double2) > MAX_LDS_BYTES || in == out) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(fft_big_first_kernel, dim3(n / FFTB, nbatch), dim3(FFTB_THREADS), sizeof(double2) * (size_t)FFTB, s,
+                       reinterpret_cast<const double2 *>(in), reinterpret_cast<double2 *>(out),
+                       reinterpret_cast<const double2 *>(twb), n, log2n, inverse);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(fft_big_late_kernel, dim3(FFTB / FFTB_COLS, nbatch), dim3(FFTB_THREADS),
+                       sizeof(double2) * (size_t)rows * FFTB_COLS, s, reinterpret_cast<double2 *>(out),
+                       reinterpret_cast<const double2 *>(twn), n, log2n, inverse);
     LAUNCH_CHECK();
     return 0;
 }

@@ -185,19 +185,21 @@ __device__ __forceinline__ float detector(float zx, float zy)
 
 /*
  * costas_frame[] of one symbol (qpsk.c:197) from the phase the loop held BEFORE that symbol's step -- what the
- * consumer of a phase record computes, operation for operation what the step itself formed (T, then the quadrant).
+ * consumer of a phase record computes: the library's sin/cos of that phase (raw polynomials, then the quadrant
+ * applied to the PAIR (sin, cos), which costs what applying it to the product would), then the reference's four
+ * products and two sums as they stand.  (The serial wave itself forms T = d (C - jS) on the raw values and leaves
+ * the quadrant out -- its detector does not need it; turning T instead of (sin, cos) here would give the same
+ * numbers except for the SIGN OF AN EXACT ZERO: x + (-x) is +0 whichever way round, so negating a sum that
+ * cancelled does not negate it.  A zero symbol -- the pick past the end of a block at CYCLES = 4, SURVEY Q5 -- met
+ * exactly that; tests/test_abi.py::test_streams_rx_pcm_host_equals_the_device_pointer_calls.)
  * FIRST = the frame's first symbol: its phase may be a loaded -0, so it takes the form that is exact there too,
  * like the step that consumed it.
  */
 template <bool FIRST>
 __device__ __forceinline__ float2 derotate(float phase, float2 d)
 {
-    if (FIRST) {
-        const SinCos w = sincos_f32(phase);
-        return make_float2(d.x * w.c + d.y * w.s, d.y * w.c - d.x * w.s);
-    }
-    const SinCosRaw w = sincos_raw_horner(phase);
-    return apply_quadrant(d.x * w.c + d.y * w.s, d.y * w.c - d.x * w.s, w.n);
+    const SinCos w = FIRST ? sincos_f32(phase) : sincos_from_raw(sincos_raw_horner(phase));
+    return make_float2(d.x * w.c + d.y * w.s, d.y * w.c - d.x * w.s);
 }
 
 template <bool FAST_CLAMP>

@@ -828,9 +828,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
  * 128-sample block it loaded: 4 VGPRs per frame), so there is no history copy through LDS and no window to zero.
  * Rings, records, flush and the serial wave are those of rx_fused_pipe_kernel (costas_wave, flush_records).
  * ======================================================================== */
-#ifndef QPSK_PIPE2_MAXFIR
-#define QPSK_PIPE2_MAXFIR 9  /* FIR waves per workgroup: 9 = three per SIMD (at most 168 VGPRs), 6 = two per SIMD */
-#endif
+#define QPSK_PIPE2_MAXFIR 9  /* FIR waves per workgroup: three per SIMD, so at most 168 VGPRs.  (Two per SIMD with three units
+                                each and a deeper LDS prefetch in 256 VGPRs: 0.31 against 0.29 ms at 8192 frames.) */
 #ifndef QPSK_PIPE2_ASM
 #define QPSK_PIPE2_ASM 1     /* 1: the FIR step as the generated instruction stream fir_r2_asm.h; 0: the compiler's (A/B builds) */
 #endif
@@ -865,10 +864,17 @@ struct Unit {
 };
 } // namespace pipe2
 
+/* NUW = units of this wave, unrolled: each unit's state (8 VGPRs of history, a few scalars) has its own registers.
+ * [Measured and not kept: ONE copy of the unit's code with the state selected per iteration -- 47 KB of kernel
+ * instead of 79 KB, no more instruction fetches beyond the cache two CUs share (the unrolled form reads 6 % more
+ * bytes than the batch holds, PMC FETCH_SIZE) -- but the register allocator then reloads spilled loop invariants
+ * right behind the sample prefetch, and a scratch reload waits for every load issued before it: 0.356 against
+ * 0.32 ms at 8192 frames on the same box.] */
 template <int NUW>
 __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *mywin, float2 *dring, float *zring, int G,
                                           int widx, int u0, int f0, int lane, int nchunks, int *status)
 {
+    constexpr int nuw = NUW;
     using namespace pipe2;
     using GM = GeomNarrow;    /* ring geometry (S, DSTRIDE, ZSTRIDE) shared with costas_wave / flush_records */
     constexpr int DSTRIDE = GM::DSTRIDE;
@@ -1058,11 +1064,9 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
             if (mine) flush_records<GM, R>(a, zring, dring, g, frame, q, c - DR);
             tick(1);
         }
-        if (g < G) {
-            float2 *dw = dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q;
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                dw[r] = fir_gain(make_float2(ac[r].x, ac[r].y));
+        if (g < G) {   /* the lane's two symbols are one aligned 16-byte word of the ring (rows are 16-byte aligned, R q even) */
+            const float2 s0 = fir_gain(make_float2(ac[0].x, ac[0].y)), s1 = fir_gain(make_float2(ac[1].x, ac[1].y));
+            *reinterpret_cast<float4 *>(dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q) = make_float4(s0.x, s0.y, s1.x, s1.y);
         }
         if (lane == 0) st_release(&sm->ready[U.u], c + 1);
         tick(4);
@@ -1085,7 +1089,7 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
         if (ok)
 #pragma unroll
             for (int ui = 0; ui < NUW; ui++) {
-                const int g = UF * un[ui].u + fl, frame = f0 + g;
+                const int g = UF * (u0 + ui) + fl, frame = f0 + g;
                 for (int c = max(0, nchunks - DR); c < nchunks; c++)
                     if (g < G && frame < a.nframes) flush_records<GM, R>(a, zring, dring, g, frame, q, c);
             }
@@ -1094,7 +1098,7 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
 #ifdef QPSK_PIPE_PROFILE
     if (prof && lane == 0)
         printf("FIR wave %d (%d units): %d chunks; cycles per chunk: wait for the loop %llu, flush %llu, window staging %llu, "
-               "filter %llu, ring hand-over %llu\n", widx, NUW, nchunks, tacc[0] / nchunks, tacc[1] / nchunks, tacc[2] / nchunks,
+               "filter %llu, ring hand-over %llu\n", widx, nuw, nchunks, tacc[0] / nchunks, tacc[1] / nchunks, tacc[2] / nchunks,
                tacc[3] / nchunks, tacc[4] / nchunks);
 #endif
 }
@@ -1136,9 +1140,7 @@ rx_pipe2_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
         widx += cv != 0;
     }
     float2 *mywin = win + (size_t)widx * UF * WS;
-    if (MAX_UW >= 3 && mine >= 3)
-        fir_wave2<(MAX_UW >= 3 ? 3 : 1)>(a, sm, mywin, dring, zring, G, widx, u0, f0, lane, nchunks, status);
-    else if (mine == 2)
+    if (mine == 2)
         fir_wave2<2>(a, sm, mywin, dring, zring, G, widx, u0, f0, lane, nchunks, status);
     else
         fir_wave2<1>(a, sm, mywin, dring, zring, G, widx, u0, f0, lane, nchunks, status);

@@ -34,7 +34,7 @@ constexpr int TF_THREADS = 256;
 
 __global__ void __launch_bounds__(TF_THREADS)
 timing_fft_kernel(const float2 *__restrict__ x, int nframes, int frame_size, int cycles, const float *__restrict__ taps_g,
-                  const double2 *__restrict__ tw, const double2 *__restrict__ cs, int32_t *index)
+                  const double2 *__restrict__ tw, const double2 *__restrict__ cs, int32_t *index, float2 *yout, double2 *Xout)
 {
     __shared__ float taps[128];
     __shared__ float2 xs[TF_NFFT + HIST];
@@ -52,12 +52,18 @@ timing_fft_kernel(const float2 *__restrict__ x, int nframes, int frame_size, int
         for (int k = 0; k < NTAPS; k++)
             fir_mac(y, xs[o + k], taps[k]);
         y = fir_gain(y);
+        if (yout) yout[(size_t)f * TF_NFFT + o] = y;          /* the estimator's view of rrc_fir(): tests compare it with rrc_fir_kernel */
         const double pr = (double)y.x * (double)y.x, pi = (double)y.y * (double)y.y;
         const int r = (int)(__brev((unsigned)o) >> (32 - LOG2N));
         v[r] = make_double2(pr + pi, 0.0);
     }
     __syncthreads();
     fft_lds_stages(v, tw, TF_NFFT, LOG2N, tid, TF_THREADS, -1.0);
+    if (Xout) {                                               /* the whole spectrum as fftn() returns it (fft.c:117-119): tests compare it with fft_kernel */
+        __syncthreads();
+        for (int o = tid; o < TF_NFFT; o += TF_THREADS)
+            Xout[(size_t)f * TF_NFFT + o] = make_double2(v[o].x / (double)TF_NFFT, v[o].y / (double)TF_NFFT);
+    }
     if (tid == 0) {
         const double dn = (double)TF_NFFT;
         const double2 raw = v[TF_NFFT / cycles];
@@ -73,11 +79,12 @@ timing_fft_kernel(const float2 *__restrict__ x, int nframes, int frame_size, int
 }
 
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
-                      const double *cs, int32_t *index, hipStream_t s)
+                      const double *cs, int32_t *index, float *yout, double *Xout, hipStream_t s)
 {
     hipLaunchKernelGGL(timing_fft_kernel, dim3(nframes), dim3(TF_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
                        nframes, frame_size, cycles, taps, reinterpret_cast<const double2 *>(tw),
-                       reinterpret_cast<const double2 *>(cs), index);
+                       reinterpret_cast<const double2 *>(cs), index, reinterpret_cast<float2 *>(yout),
+                       reinterpret_cast<double2 *>(Xout));
     return (int)hipGetLastError();
 }
 

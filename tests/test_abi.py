@@ -109,3 +109,75 @@ def test_bad_arguments_are_rejected(qpsk_lib):
     p = Params(9600.0, 2400.0, 510, .35, .06, -1.0, 1.0, 0, 0)  # 510 % 4 != 0
     h = C.c_void_p()
     assert qpsk_lib.qpsk_ctx_create(C.byref(h), 0, C.byref(p), None) < 0
+
+
+@pytest.mark.gpu
+def test_dropin_rx_frame_reports_a_flagged_block(qpsk_lib, tmp_path):
+    """a kernel that flags its results (here: a loop phase beyond the bounded 2 pi wrap, provoked through the reference's
+    own control surface, set_alpha(1e12f)) must not be swallowed by the void drop-in rx_frame(): the process aborts with
+    the library's message on stderr instead of returning stale symbols (the reference itself would hang in phase_wrap())"""
+    import subprocess
+    src = tmp_path / "bad.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "qpsk_dropin.h"
+int main(void)
+{
+    static int16_t pcm[512];
+    for (int i = 0; i < 512; i++) pcm[i] = (int16_t)((i * 7919) % 20000 - 10000);
+    create_control_loop(0.0628318f, -1.0f, 1.0f);
+    rrc_make(9600.0f, 2400.0f, .35f);
+    rx_frame(pcm);                       /* ordinary block: fine */
+    rx_frame(pcm);
+    printf("two ordinary blocks done\n");
+    fflush(stdout);
+    set_alpha(1e12f);                    /* costas_loop.h control surface */
+    rx_frame(pcm);
+    rx_frame(pcm);
+    printf("NOT REACHED\n");
+    return 0;
+}
+''')
+    import qpsk_amd
+    libdir = os.path.dirname(qpsk_amd.lib_path())
+    exe = str(tmp_path / "bad")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-I", os.path.join(ROOT, "include"), str(src), "-L", libdir, "-lqpsk_hip", "-lm",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert "two ordinary blocks done" in r.stdout and "NOT REACHED" not in r.stdout
+    assert r.returncode != 0 and "2 pi wrap" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_streams_rx_pcm_host_equals_the_device_pointer_calls(oracle):
+    """qpsk_streams_rx_pcm_host (one upload, one download, one synchronisation per block: what the drop-in rx_frame()
+    runs on) gives the bits of the oracle's modem block after block, loop state in and out included"""
+    import numpy as np
+    import qpsk_amd
+    from sigutil import bits_equal
+    fs, rs, L, S, B = 9600.0, 2400.0, 512, 3, 6
+    m = qpsk_amd.Modem(fs=fs, rs=rs, frame_size=L)
+    m.streams_reset(S, 1500.0)
+    rng = np.random.default_rng(3)
+    om = [oracle.modem(fs, rs, L, loop_bw=np.float32(2.0 * 3.14159265358979323846 / 100.0)) for _ in range(S)]
+    for o in om:
+        o.set_mixer_hz(1500.0)
+    N = m.nsym
+    for k in range(B):
+        pcm = (6000 * rng.standard_normal((S, L))).astype(np.int16)
+        st = np.array([[o.phase, o.freq] for o in om], np.float32)
+        if k == 3:                         # the caller edits the state between blocks (set_phase()/set_frequency())
+            st[:, 0] += np.float32(0.25)
+            for i, o in enumerate(om):
+                o.s.loop.phase = st[i, 0]
+        sym = np.zeros((S, N), np.uint8); cos = np.zeros((S, N, 2), np.float32); idx = np.zeros(S, np.int32)
+        rc = m.L.qpsk_streams_rx_pcm_host(m.h, C.c_void_p(pcm.ctypes.data), C.c_void_p(st.ctypes.data), C.c_void_p(sym.ctypes.data),
+                                          C.c_void_p(cos.ctypes.data), C.c_void_p(idx.ctypes.data))
+        assert rc == 0, m.L.qpsk_last_error()
+        for i, o in enumerate(om):
+            o.rx_pcm(pcm[i])
+            assert idx[i] == o.index and bits_equal(sym[i], o.symbols), (k, i)
+            bad = np.nonzero(cos[i].view(np.uint32) != o.costas_frame.view(np.uint32))[0]
+            assert bad.size == 0, "block %d stream %d: costas_frame differs at symbols %s: %s vs %s" % (
+                k, i, bad[:8], cos[i][bad[:4]], o.costas_frame[bad[:4]])
+            assert st[i, 0] == o.phase and st[i, 1] == o.freq, (k, i)

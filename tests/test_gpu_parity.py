@@ -527,14 +527,22 @@ def test_costas_zero_error_and_signed_zero_state(oracle):
 def test_fft_batch(oracle):
     rng = np.random.default_rng(4)
     m = modem()
-    for n in (1, 2, 8, 512, 2048, 8192):
-        x = rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))
+    # up to 8192 points one workgroup holds the transform in LDS; above, two passes over global memory (the frame
+    # lengths of the BASELINE configs: 16384 and 2^20; fft.c:110-136 take any power of two)
+    for n, nb in ((1, 5), (2, 5), (8, 5), (512, 5), (2048, 5), (8192, 5), (16384, 3), (65536, 2), (1 << 20, 2), (1 << 21, 1)):
+        x = rng.standard_normal((nb, n)) + 1j * rng.standard_normal((nb, n))
         X = cpu(m.fft(x))
         Xi = cpu(m.fft(x, inverse=True))
         m.sync()
-        for b in range(5):
+        for b in range(nb):
             assert bits_equal(X[b], oracle.fftn(x[b])), n       # same host libm builds both twiddle sets
             assert bits_equal(Xi[b], oracle.ifftn(x[b])), n
+    import torch
+    xin = torch.from_numpy(x).cuda()                            # in place (the reference copies in -> out first, fft.c:99-101)
+    assert m.L.qpsk_fft_batch(m.h, C.c_void_p(xin.data_ptr()), C.c_void_p(xin.data_ptr()), 1, 1 << 21, 0) == 0
+    m.sync()
+    assert bits_equal(cpu(xin)[0], X[0])
+    assert m.L.qpsk_fft_batch(m.h, C.c_void_p(xin.data_ptr()), C.c_void_p(xin.data_ptr()), 1, 1 << 22, 0) == -2
     g = golden("fft_bits.npz")
     np.testing.assert_allclose(cpu(m.fft(g["x512"][None]))[0], g["fft512"], rtol=0, atol=1e-15)
     assert np.all(cpu(m.fft(np.eye(1, 512, dtype=np.complex128)))[0] == 2.0 ** -9)
@@ -793,3 +801,54 @@ def test_caller_stream_ordering_contract(oracle):
             del junk2
     m.sync()
     m.set_stream(None)
+
+
+# ------------------------------------------------------------------ config 3: what is pinned inside the FFT timing estimate
+def test_fft_timing_internals_are_the_pinned_stages(oracle):
+    """The FFT timing estimate has no reference counterpart (the reference never calls fft.c), but everything below
+    its final argmax IS reference code: its 512 filtered samples are rrc_fir() outputs (rrc_fir.c:17-30: equal to
+    qpsk_rrc_fir_batch, which the reference fixtures pin) and its spectrum is fftn() (fft.c:110-120: equal to
+    qpsk_fft_batch, pinned likewise).  Only "index = first argmax of Re(X_k e^{+j 2 pi i / CYCLES})" is this build's own
+    definition, and that rule is checked against the oracle's restatement."""
+    from oracle.pyoracle import TIMING_FFT
+    fs, rs, L, F = 19200.0, 2400.0, 2048, 24
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT)
+    x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=35.0, base_seed=3, noise=0.1)
+    x[5] = random_frames(1, L, seed=9)[0]
+    idx, y, X = m.timing_fft(x, want_internals=True)
+    m.sync()
+    full = cpu(m.rrc_fir(x))                                   # (F, L, 2): the full-rate filter, fresh delay lines
+    assert bits_equal(cpu(y), full[:, 128:128 + 512])
+    p = (cpu(y)[..., 0].astype(np.float64) ** 2 + cpu(y)[..., 1].astype(np.float64) ** 2).astype(np.complex128)
+    assert bits_equal(cpu(X), cpu(m.fft(p)))                   # same transform, same host-built twiddles
+    Xh = cpu(X)[:, 512 // 8]
+    import math                                                # libm's cos/sin, like the host table (numpy's may round differently)
+    cand = np.stack([Xh.real * math.cos(TAU * i / 8.0) - Xh.imag * math.sin(TAU * i / 8.0) for i in range(8)], axis=1)
+    assert np.array_equal(cpu(idx), np.argmax(cand, axis=1))   # the rule itself (first maximum)
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FFT)
+    assert np.array_equal(cpu(idx), want["index"])
+
+
+def test_full_size_config3_properties(oracle):
+    """BASELINE config 3 at full size (4096 x 16384 with the FFT timing estimate in front): (a) every clean frame's
+    estimate is the eye centre 126 mod 8 = 6, (b) so the whole batch equals the fixed-index batch bit for bit, (c) a spread
+    sample of frames equals the oracle's FFT-timing result, (d) every loop ends on the +50 Hz offset"""
+    import torch
+    import bench
+    from oracle.pyoracle import TIMING_FFT
+    fs, rs, L, F = bench.FS, bench.RS, 16384, 4096
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT)
+    x = bench.synth_frames_gpu(torch, torch.device("cuda", 0), F, m.taps, seed=5)
+    a = m.rx_batch(x)
+    m.sync()
+    assert np.all(cpu(a["index"]) == 6)
+    mf = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    b = mf.rx_batch(x)
+    mf.sync()
+    for k in ("sym", "phase", "freq", "hz"):
+        assert bits_equal(cpu(a[k]), cpu(b[k])), k
+    pick = np.unique(np.concatenate([np.arange(0, F, 257), [1, F - 1]]))
+    want = oracle.rx_batch(x[torch.from_numpy(pick).cuda()].cpu().numpy(), fs, rs, loop_bw=BW, timing_mode=TIMING_FFT)
+    for k in ("sym", "phase", "freq", "index"):
+        assert bits_equal(cpu(a[k])[pick], want[k].astype(cpu(a[k]).dtype)), k
+    assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)

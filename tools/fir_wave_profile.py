@@ -30,7 +30,7 @@ for frames in (4096, 8192):
     ph = torch.empty_like(fr)
     for st in settings:
         m.tune(pipe_layout_lo=None, pipe_layout_hi=None)
-        m.tune(**{k: int(v, 0) for k, v in st.items()})
+        m.tune(**{k: int(str(v), 0) for k, v in st.items()})
         try:
             for _ in range(3):
                 m.rx_batch_raw(x, frames, sym, fr, ph)

@@ -1,15 +1,25 @@
 # measurement session behind profiles/ (run on the GPU box, one gpurun call); then: python tools/collect_profiles.py <tag>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
-set -e
 python3 bench.py > $O/bench.json 2> $O/bench.err
+python3 bench.py --steps 20 --warmup 5 --cpu-frames 0 > $O/bench20.json 2> $O/bench20.err
+python3 bench.py --frames 8192 --cpu-frames 0 > $O/bench8192.json 2> $O/bench8192.err
+python3 bench.py --gpus 2 --cpu-frames 0 > $O/bench_gpus2_shared.json 2> $O/bench_gpus2_shared.err     # two ranks on this box's one GPU: the launch path, not a scaling number
 prof() { d=$1; shift; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$d -- "$@" > $O/$d.log 2>&1; }
 prof prof_bench python3 bench.py --cpu-frames 0        # bench.py's default steps and warmup: the same command, CPU leg off
-prof prof_8192 python3 tools/sweep.py --frames 8192
+prof prof_bench20 python3 bench.py --steps 20 --warmup 5 --cpu-frames 0   # the driver's command
+prof prof_8192 python3 bench.py --frames 8192 --cpu-frames 0
 prof prof_fft python3 tools/sweep.py --timing fft
 prof prof_hist2 python3 tools/sweep.py --timing hist
 prof prof_streams3 python3 tools/bench_streams.py
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 5 --warmup 1 --cpu-frames 0 --no-parity > $O/pmc_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 5 --warmup 1 --cpu-frames 0 --no-parity > $O/pmc_write.log 2>&1
+pmcrun() { d=$1; c=$2; shift 2; timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/$d -- "$@" > $O/$d.log 2>&1; }
+pmcrun pmc_fetch FETCH_SIZE python3 bench.py --steps 5 --warmup 1 --cpu-frames 0 --no-parity
+pmcrun pmc_write WRITE_SIZE python3 bench.py --steps 5 --warmup 1 --cpu-frames 0 --no-parity
+pmcrun pmc_fetch_8192 FETCH_SIZE python3 bench.py --frames 8192 --steps 5 --warmup 1 --cpu-frames 0 --no-parity
+pmcrun pmc_write_8192 WRITE_SIZE python3 bench.py --frames 8192 --steps 5 --warmup 1 --cpu-frames 0 --no-parity
+pmcrun pmc_fft_fetch FETCH_SIZE python3 tools/sweep.py --frames 4096 --timing fft --rounds 1 --per-round 2
+pmcrun pmc_fft_write WRITE_SIZE python3 tools/sweep.py --frames 4096 --timing fft --rounds 1 --per-round 2
 timeout -k 10 300 python3 tools/fir_wave_profile.py > $O/fir_wave_profile_final.log 2>&1
-cat $O/bench.json
+timeout -k 10 300 python3 tools/bench_dropin.py 2000 > $O/dropin.log 2>&1
+timeout -k 10 300 python3 tools/bench_config5.py > $O/config5.log 2>&1
+cat $O/bench.json; cat $O/bench8192.json | cut -c1-300; cat $O/bench_gpus2_shared.json | cut -c1-300; tail -3 $O/dropin.log
