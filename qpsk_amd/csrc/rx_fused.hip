@@ -45,7 +45,12 @@
 #include "qpsk_device.h"
 #include "costas_asm.h"
 #include "fir_r2_asm.h"
+#include "fir_r4_asm.h"
 #include "kernels.h"
+
+#ifndef QPSK_PIPE1_ASM
+#define QPSK_PIPE1_ASM 1     /* rx_fused_pipe_kernel: FIR steps as the generated streams; 0: the compiler's pinned step (A/B builds) */
+#endif
 
 namespace qpsk {
 
@@ -86,8 +91,10 @@ struct Geom {
     static constexpr int TSTEPS = NTAPS + C * (R - 1);   /* window positions a lane sweeps per chunk */
     static constexpr int PAD = R * C;        /* lanes of a frame are PAD positions apart: position p lives at slot p + p/PAD */
     static constexpr int WL = CH + 128;      /* window positions kept per frame */
-    /* padded; frame stride = 16 (mod 32) slots: the two frames of a 32-lane LDS pass use complementary banks */
-    static constexpr int WSLOTS = ((WL + WL / (2 * C) + 1 + 31) / 32) * 32 + 16;   /* room for the tightest padding used: 2-symbol lanes */
+    /* padded image (two pad slots per PAD positions, see the FIR waves): 716 slots for the two-symbol lanes; frame
+     * stride = 0 (mod 32) slots = 0 (mod 64) banks: the four frames whose lanes share a ds_read_b128 pass start in
+     * bank quads 4q, which the 16 lanes of a pass then cover exactly once */
+    static constexpr int WSLOTS = ((WL + 2 * (WL / (2 * C)) + 31) / 32) * 32;
     static constexpr int DSTRIDE = DR * S + 2;   /* float2 slots per frame row: 16-byte aligned rows (the Costas wave reads two
                                                     symbols per ds_read_b128), 4 dwords (mod 64) apart: lanes hit different bank quads */
     static constexpr int ZSTRIDE = DR * S + 4;   /* 4-byte records (the phase a step started from) per Costas row: 16-byte
@@ -216,7 +223,11 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
         ok = wait_ge(&sm->ready[gw], c + 1, &sm->abort_flag);
         if (!__all(ok)) { ok = false; break; }
 #ifdef QPSK_PIPE_PROFILE
-        ctick(cw);
+        {
+            const unsigned long long before = cw;
+            ctick(cw);
+            if (cprof && lane == 0 && (a.dbg & 2048) && (c < 4 || c % 8 == 0)) printf("  serial wave: chunk %d waited %llu cycles\n", c, cw - before);
+        }
 #endif
         const int slot = (c % DR) * S;
         const int cnt = min(S, N - c * S);
@@ -484,9 +495,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         sm->taps[i] = i < NTAPS ? a.taps[i] : 0.0f;
     if (tid < MAX_WAVES) sm->ready[tid] = 0;
     if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
-    for (int i = tid; i < G * WSLOTS; i += blockDim.x)
-        win[i] = make_float2(0.0f, 0.0f);
-    __syncthreads();
+    __syncthreads();      /* (no window to zero: a fresh delay line is a zero history in the FIR waves' registers) */
 
     if (wave == 0) {
         costas_wave<GM>(a, sm, dring, zring, G, f0, lane, nchunks, status);
@@ -525,6 +534,10 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
 
   auto fir_wave = [&](auto wmap) {
     /* this wave's lane mapping: QL lanes per frame, R symbols per lane (QL * R = S for every wave of the workgroup) */
+    /* window image: position p at slot p + PADS (p / PAD), PADS = 2 -- lanes are 16-byte multiples apart (272 bytes for
+     * four symbols per lane, 144 for two), so positions (t, t+1), t even, are one aligned 16-byte word, which is what
+     * the hand-scheduled filter streams read (fir_r4_asm.h, fir_r2_asm.h: one ds_read_b128 per two positions) */
+    constexpr int PADS = 2;
     constexpr int QL = decltype(wmap)::QL, R = decltype(wmap)::R, FWV = 64 / QL, PAD = R * C,
                   TSTEPS = NTAPS + C * (R - 1);
     static_assert(QL * R == S && 128 % PAD == 0 && PAD >= 2 * C, "chunk size and window padding are the workgroup's");
@@ -542,6 +555,9 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         float2 *wf;                /* this lane's frame window */
         const float2 *rd;          /* FIR read base: position PAD*q -> slot (PAD+1)*q */
         int wr0[FWV], wr1[FWV];    /* window write slots of the loaded pair, per frame of the wave */
+        bool even[FWV];            /* the frame's decimation offset is even: the pair is one aligned 16-byte word */
+        bool h0[FWV], h1[FWV];     /* per lane: the pair's first / second sample of the LAST block of a chunk is history of the next */
+        float4 hist[FWV];          /* per lane: the pair it loaded from the last block of the previous chunk */
         const float4 *src[FWV];
         bool fv[FWV];
     };
@@ -553,15 +569,19 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         cx.fvalid = cx.frame < a.nframes;
         cx.all_valid = f0 + gbase + FWV <= a.nframes;
         cx.wf = win + (size_t)cx.g * WSLOTS;
-        cx.rd = cx.wf + (PAD + 1) * q;
+        cx.rd = cx.wf + (PAD + PADS) * q;
 #pragma unroll
         for (int ff = 0; ff < FWV; ff++) {
             const int fr = f0 + gbase + ff;
             cx.fv[ff] = fr < a.nframes;
             const int ix = a.index ? (cx.fv[ff] ? a.index[fr] : 0) : a.fixed_index;   /* decimation offset, < C */
             const int p0 = 2 * lane + 126 - ix;               /* window position of sample 2*lane of the chunk */
-            cx.wr0[ff] = (gbase + ff) * WSLOTS + p0 + p0 / PAD;
-            cx.wr1[ff] = (gbase + ff) * WSLOTS + (p0 + 1) + (p0 + 1) / PAD;
+            cx.wr0[ff] = (gbase + ff) * WSLOTS + p0 + PADS * (p0 / PAD);
+            cx.wr1[ff] = (gbase + ff) * WSLOTS + (p0 + 1) + PADS * ((p0 + 1) / PAD);
+            cx.even[ff] = (ix & 1) == 0;
+            cx.h0[ff] = p0 >= 128;                            /* position p0 - 128 of the next chunk's window exists */
+            cx.h1[ff] = p0 + 1 >= 128;
+            cx.hist[ff] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   /* a fresh delay line (qpsk.c:37) */
             cx.src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(cx.fv[ff] ? fr : 0) * L);
         }
         return cx;
@@ -624,33 +644,29 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     };
 
     /* one chunk of one frame group: flush what the loop has finished with, stage the window, filter, hand over */
-    auto run_chunk = [&](const Ctx &cx, float4 (&pre)[FWV][NLD], int c, bool prefetch_next) -> bool {
-        float2 *wf = cx.wf;
-        /* history: positions [0, 126-idx) <- [CH, CH+126-idx) of the previous window (zeros for c = 0) */
-        {
-            /* 128 positions by the frame's QL lanes: p = q + QL*i -> slot p + p/PAD = hq + QL*i + (QL*i)/PAD
-             * (q % PAD + (QL*i) % PAD < PAD in both mappings) */
-            constexpr int HN = 128 / QL, HB = HN < 8 ? HN : 8;
-            const int hq = q + q / PAD;
-#pragma unroll
-            for (int i0 = 0; i0 < HN; i0 += HB) {   /* 8 at a time (source and destination ranges are disjoint) */
-                float2 h[HB];
-#pragma unroll
-                for (int i = 0; i < HB; i++)
-                    h[i] = wf[CH + CH / PAD + hq + QL * (i0 + i) + (QL * (i0 + i)) / PAD];
-#pragma unroll
-                for (int i = 0; i < HB; i++)
-                    wf[hq + QL * (i0 + i) + (QL * (i0 + i)) / PAD] = h[i];
-            }
-        }
-        /* new samples of this chunk (prefetched), then start the next chunk's loads */
+    auto run_chunk = [&](Ctx &cx, float4 (&pre)[FWV][NLD], int c, bool prefetch_next) -> bool {
+        /* The window is rebuilt from REGISTERS every chunk: the 126 samples of history a frame carries are the tail
+         * of the last 128-sample block its wave loaded for the previous chunk (4 VGPRs per frame), written one block
+         * below block 0; then the prefetched samples of this chunk.  No copy through LDS, nothing to zero.  An even
+         * decimation offset makes a lane's pair one aligned 16-byte word of the image. */
+        constexpr int BLK = 128 + PADS * (128 / PAD);
 #pragma unroll
         for (int ff = 0; ff < FWV; ff++) {
+            if (cx.even[ff]) {      /* wave-uniform: every lane holds a pair of frame ff here */
+                if (cx.h0[ff]) *reinterpret_cast<float4 *>(win + cx.wr0[ff] - BLK) = cx.hist[ff];
 #pragma unroll
-            for (int j = 0; j < NLD; j++) {
-                win[cx.wr0[ff] + (128 + 128 / PAD) * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
-                win[cx.wr1[ff] + (128 + 128 / PAD) * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
+                for (int j = 0; j < NLD; j++)
+                    *reinterpret_cast<float4 *>(win + cx.wr0[ff] + BLK * j) = pre[ff][j];
+            } else {
+                if (cx.h0[ff]) win[cx.wr0[ff] - BLK] = make_float2(cx.hist[ff].x, cx.hist[ff].y);
+                if (cx.h1[ff]) win[cx.wr1[ff] - BLK] = make_float2(cx.hist[ff].z, cx.hist[ff].w);
+#pragma unroll
+                for (int j = 0; j < NLD; j++) {
+                    win[cx.wr0[ff] + BLK * j] = make_float2(pre[ff][j].x, pre[ff][j].y);
+                    win[cx.wr1[ff] + BLK * j] = make_float2(pre[ff][j].z, pre[ff][j].w);
+                }
             }
+            cx.hist[ff] = pre[ff][NLD - 1];
         }
         if (prefetch_next) prefetch(cx, pre, c + 1);
         tick(2);
@@ -679,7 +695,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                     for (int u = 0; u < C; u++) {
                         const int t = tb * C + u;
                         if (t < TSTEPS) {
-                            const float2 v = rd[t + t / PAD];
+                            const float2 v = rd[t + PADS * (t / PAD)];
 #pragma unroll
                             for (int r = 0; r < R; r++) {
                                 const int k = t - C * r;
@@ -688,6 +704,19 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                         }
                     }
                 }
+            }
+        } else if (QPSK_PIPE1_ASM && !QPSK_ABLATE(a, 1)) {
+            /* the hand-scheduled streams (generated, tools/gen_fir_asm.py): the sum of the step below, same order */
+            if constexpr (R == 2) {
+                v2f a0, a1;
+                fir_r2_asm(lds_addr(rd), lds_addr(sm->taps), a0, a1);
+                acc[0] = make_float2(a0.x, a0.y);
+                acc[1] = make_float2(a1.x, a1.y);
+            } else {
+                v2f a0, a1, a2, a3;
+                fir_r4_asm(lds_addr(rd), lds_addr(sm->taps), a0, a1, a2, a3);
+                acc[0] = make_float2(a0.x, a0.y); acc[1] = make_float2(a1.x, a1.y);
+                acc[R > 2 ? 2 : 0] = make_float2(a2.x, a2.y); acc[R > 2 ? 3 : 1] = make_float2(a3.x, a3.y);
             }
         } else if (!QPSK_ABLATE(a, 1)) { /* measurement build only: skip the filter arithmetic, keep the traffic */
             /* Software pipeline, one block of C window positions deep: the LDS reads of block tb+1 (window values
@@ -714,7 +743,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
 #pragma unroll
                 for (int u = 0; u < C; u++) {
                     const int t = tb * C + u;
-                    if (t < TSTEPS) wv[tb & 1][u] = rd[t + t / PAD];
+                    if (t < TSTEPS) wv[tb & 1][u] = rd[t + PADS * (t / PAD)];
                 }
             };
             v2f ac[R];
@@ -780,7 +809,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         return true;
     };
 
-    const Ctx own = make_ctx();
+    Ctx own = make_ctx();
     float4 pre[FWV][NLD];
     prefetch(own, pre, 0);
     bool ok = true;

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Generator of qpsk_amd/csrc/fir_r2_asm.h: the two-symbols-per-lane RRC FIR step of rx_pipe2_kernel as ONE
-hand-scheduled gfx950 instruction stream (rrc_fir.c:22-26 evaluated at the two decimated outputs a lane owns).
+"""Generator of qpsk_amd/csrc/fir_r2_asm.h and fir_r4_asm.h: the RRC FIR step of the pipeline kernels' FIR waves
+(R = 2 or 4 consecutive decimated outputs per lane) as ONE hand-scheduled gfx950 instruction stream (rrc_fir.c:22-26
+evaluated at the decimated outputs a lane owns).
 
-    python tools/gen_fir_asm.py > qpsk_amd/csrc/fir_r2_asm.h
+    python tools/gen_fir_asm.py 1 100 2 > qpsk_amd/csrc/fir_r2_asm.h      # depth, first VGPR, R
+    python tools/gen_fir_asm.py 1 168 4 > qpsk_amd/csrc/fir_r4_asm.h
 
 Why a generated stream and not C++: the compiler's version of the same sum (asm-pinned product/add order) carries
 ~60 v_mov and ~60 s_nop per 508 packed multiply/adds, and fetches LDS only one block of 8 window positions ahead --
@@ -19,21 +21,23 @@ positions (t, t+1), t even, are one aligned 16-byte word; taps as 128 floats in 
 """
 import sys
 
-NTAPS, C, R = 127, 8, 2
-TSTEPS = NTAPS + C * (R - 1)          # 135 window positions
-NB = (TSTEPS + C - 1) // C            # 17 blocks of 8 positions
+NTAPS, C = 127, 8
 DEPTH = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-NW, NG = DEPTH + 1, DEPTH + 2         # live window blocks / tap groups
 V0 = int(sys.argv[2]) if len(sys.argv) > 2 else 76   # first VGPR of the block's fixed registers (even)
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 2     # symbols per lane
+TSTEPS = NTAPS + C * (R - 1)          # 135 (R = 2) or 151 (R = 4) window positions
+NB = (TSTEPS + C - 1) // C            # blocks of 8 positions
+NW, NG = DEPTH + 1, DEPTH + R         # live window blocks / tap groups (symbol r reaches back r groups)
+PAD = R * C                           # lanes are PAD positions apart: position p at slot p + 2*(p/PAD)
 
 W0 = V0                               # window blocks: NW x 16 dwords
 T0 = W0 + 16 * NW                     # tap groups:    NG x 8 dwords
-P0 = T0 + 8 * NG                      # products:      4 pairs
-VEND = P0 + 8                         # first register NOT used
+P0 = T0 + 8 * NG                      # products:      2 positions x R symbols, one pair each
+VEND = P0 + 4 * R                     # first register NOT used
 
 
 def slot_of(p):
-    return p + 2 * (p // 16)
+    return p + 2 * (p // PAD)
 
 
 def wreg(t):
@@ -74,8 +78,8 @@ def main():
     reads = {}     # block -> number of LDS reads issued for it
     for d in range(min(DEPTH, NB)):
         reads[d] = fetch(d, out)
-    out.append('"v_mov_b64 %[a0], 0\\n\\tv_mov_b64 %[a1], 0\\n\\t"')     # y = 0 (rrc_fir.c:22)
-    acc = ["%[a0]", "%[a1]"]
+    out.append('"' + "".join("v_mov_b64 %%[a%d], 0\\n\\t" % r for r in range(R)) + '"')     # y = 0 (rrc_fir.c:22)
+    acc = ["%%[a%d]" % r for r in range(R)]
     for b in range(NB):
         if b + DEPTH < NB:
             reads[b + DEPTH] = fetch(b + DEPTH, out)
@@ -98,40 +102,46 @@ def main():
             out += muls + adds
     body = "\n        ".join(out)
     clob = ", ".join('"v%d"' % r for r in range(V0, VEND))
+    nmul = sum(1 for x in out if "v_pk_mul" in x)
+    args = ", ".join("v2f &acc%d" % r for r in range(R))
+    decl = ", ".join("a%d" % r for r in range(R))
+    outs = ", ".join('[a%d] "=&v"(a%d)' % (r, r) for r in range(R))
+    copy = "\n".join("    acc%d = a%d;" % (r, r) for r in range(R))
     print('''/*
- * fir_r2_asm.h -- GENERATED by tools/gen_fir_asm.py %d %d; do not edit.
+ * fir_r%(R)d_asm.h -- GENERATED by tools/gen_fir_asm.py %(D)d %(V0)d %(R)d; do not edit.
  *
- * The two-symbols-per-lane RRC FIR step of rx_pipe2_kernel (rrc_fir.c:22-26 at the two decimated outputs of a
- * lane) as one hand-scheduled gfx950 instruction stream: %d packed multiplies and as many packed adds, unfused,
- * taps 0..126 in order into one (re, im) accumulator per symbol; window pairs and tap groups fetched from LDS %d
- * blocks of 8 positions ahead (counted lgkmcnt waits), no register moves, no nops.  See the generator for the layout.
- * Fixed registers v%d..v%d are scratch owned by the block.
+ * The RRC FIR step of a FIR wave with %(R)d consecutive decimated outputs per lane (rrc_fir.c:22-26 at those
+ * outputs) as one hand-scheduled gfx950 instruction stream: %(nmul)d packed multiplies and as many packed adds,
+ * unfused, taps 0..126 in order into one (re, im) accumulator per symbol; window pairs (one aligned 16-byte word
+ * per two positions: position p at slot p + 2 (p / %(PAD)d) from the lane's base) and tap groups fetched from LDS
+ * %(D)d block(s) of 8 positions ahead (counted lgkmcnt waits), no register moves, no nops.  See the generator.
+ * Fixed registers v%(V0)d..v%(VL)d are scratch owned by the block.
  */
-#ifndef QPSK_FIR_R2_ASM_H
-#define QPSK_FIR_R2_ASM_H
+#ifndef QPSK_FIR_R%(R)d_ASM_H
+#define QPSK_FIR_R%(R)d_ASM_H
 
 #include "qpsk_device.h"
 
 namespace qpsk {
 
-constexpr int FIR_R2_ASM_FIRST_VGPR = %d, FIR_R2_ASM_END_VGPR = %d;
+constexpr int FIR_R%(R)d_ASM_FIRST_VGPR = %(V0)d, FIR_R%(R)d_ASM_END_VGPR = %(VEND)d;
 
 /* rd_addr: LDS byte address of the lane's window position 0; tap_addr: LDS byte address of the 128 taps */
-__device__ __forceinline__ void fir_r2_asm(unsigned rd_addr, unsigned tap_addr, v2f &acc0, v2f &acc1)
+__device__ __forceinline__ void fir_r%(R)d_asm(unsigned rd_addr, unsigned tap_addr, %(args)s)
 {
-    v2f a0, a1;
+    v2f %(decl)s;
     asm volatile(
-        %s
+        %(body)s
         "s_waitcnt lgkmcnt(0)"
-        : [a0] "=&v"(a0), [a1] "=&v"(a1)
+        : %(outs)s
         : [rd] "v"(rd_addr), [tp] "v"(tap_addr)
-        : "memory", %s);
-    acc0 = a0;
-    acc1 = a1;
+        : "memory", %(clob)s);
+%(copy)s
 }
 
 } // namespace qpsk
-#endif''' % (DEPTH, V0, sum(1 for x in out if "v_pk_mul" in x), DEPTH, V0, VEND - 1, V0, VEND, body, clob))
+#endif''' % dict(R=R, D=DEPTH, V0=V0, VL=VEND - 1, VEND=VEND, nmul=nmul, PAD=PAD, args=args, decl=decl, body=body, outs=outs,
+                  clob=clob, copy=copy))
 
 
 if __name__ == "__main__":
