@@ -27,6 +27,19 @@
  *     silently computed on the CPU: there is NO host fallback in this library.
  *   - calls on one context are ordered on its stream; outputs are valid after
  *     qpsk_ctx_sync() (or after synchronising the stream the caller supplied).
+ *
+ * Stream ordering (the contract)
+ *   The library enqueues every kernel and copy of a context on THAT context's stream and on nothing else; it does
+ *   not order its work against any other stream of the caller.  So:
+ *     - a buffer handed to a call must have been produced on the context's stream, or the caller must have ordered
+ *       its producer before the call (event / synchronisation);
+ *     - memory that a stream-ordered allocator (PyTorch's caching allocator, hipMallocAsync pools) recycles must be
+ *       recycled in the context's stream order too: give the library the allocator's stream (qpsk_ctx_create /
+ *       qpsk_ctx_set_stream), or synchronise before handing over recycled memory.  A library stream that the
+ *       allocator does not know writes into memory whose previous contents queued kernels of the allocator's stream
+ *       still have to read (this build's round-1 abort: DESIGN.md section 1);
+ *     - outputs may be read by other streams only after an event / synchronisation on the context's stream.
+ *   NULL means the HIP default stream, with its usual implicit ordering against blocking streams.
  */
 #ifndef QPSK_HIP_H
 #define QPSK_HIP_H
