@@ -161,6 +161,12 @@ int qpsk_rrc_fir_batch(qpsk_ctx *ctx, float *d_memory, const float *d_in, float 
  * receives hist_i[k] + hist_q[k], k = 0..7 (qpsk.c:175, locals of rx_frame) as [nframes][8] */
 int qpsk_timing_hist_batch(qpsk_ctx *ctx, const float *d_filtered, int nframes, int32_t *d_index, int32_t *d_hist);
 
+/* The histogram timing estimate (qpsk.c:127-180) straight from UNFILTERED frames: rrc_fir() with a fresh delay line
+ * and the scan fused in one kernel, the filtered samples never leaving the CU (what qpsk_rx_batch runs in
+ * QPSK_TIMING_HIST mode).  Needs CYCLES = 8, frame_size a multiple of 256, 16-byte aligned input; same results as
+ * qpsk_rrc_fir_batch() followed by qpsk_timing_hist_batch().  d_index [nframes]; d_hist [nframes][8] or NULL. */
+int qpsk_timing_scan_batch(qpsk_ctx *ctx, const float *d_in, int nframes, int32_t *d_index, int32_t *d_hist);
+
 /* The FFT timing estimate alone (QPSK_TIMING_FFT; NEW DESIGN, the reference never calls fft.c: SURVEY section 0).
  *   d_index     [nframes] int32
  *   d_filtered  [nframes][512] complex float, may be NULL: the 512 rrc_fir() outputs (samples 128..639 of the frame,

@@ -65,7 +65,7 @@ struct Tuning {
     int pipe_v = -1, pipe_g = -1;                     /* 1: rx_fused_pipe_kernel, 2: rx_pipe2_kernel; frames per workgroup of the latter */
     int layout_lo = -1, layout_hi = -1;               /* rx_pipe2_kernel: units per hardware wave, 4 bits each (waves 1-5 / 6-11) */
     int pipe_variant = -1;                            /* pipeline kernel: layout bits (kernels.h, FusedArgs::dbg) */
-    int hist_generic = -1;                            /* 1: the generic timing scan instead of the CYCLES = 8 one */
+    int hist_generic = -1;                            /* histogram estimate: 1 = rrc_fir + scan kernels (no fused scan), 2 = those with the generic scan */
 };
 
 static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
@@ -236,6 +236,7 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
     HIP_TRY(hipSetDevice(device));
     KERNEL_TRY(prepare_kernels());
     KERNEL_TRY(prepare_pipe_kernel());
+    KERNEL_TRY(prepare_timing_scan());
     qpsk_ctx *c = new qpsk_ctx();
     c->device = device;
     for (const auto &k : TUNING_KEYS) {   /* the only place the environment is read */
@@ -440,6 +441,13 @@ static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32
     return QPSK_OK;
 }
 
+/* QPSK_HIST_GENERIC = 1 or 2 keeps the three-kernel path (rrc_fir -> scan -> pipeline), 2 with the any-CYCLES scan too */
+static bool scan_fused_ok(const qpsk_ctx *c, const float *d_in)
+{
+    return c->cycles == 8 && c->prm.frame_size % timing_scan_tile() == 0 && ((uintptr_t)d_in % 16) == 0 &&
+           tuned(c->tune.hist_generic, 0) == 0;
+}
+
 static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int32_t **d_index_out)
 {
     *d_index_out = nullptr;
@@ -447,12 +455,20 @@ static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int
     int rc = ensure(c, c->index, sizeof(int32_t) * (size_t)nframes);
     if (rc) return rc;
     if (c->prm.timing_mode == QPSK_TIMING_HIST) {
+        /* the fused full-rate FIR + scan kernel keeps the filtered block in LDS (timing_scan.hip): the input is read
+         * once here and once by the pipeline kernel that follows, nothing is written but the index */
+        if (scan_fused_ok(c, d_in)) {
+            KERNEL_TRY(launch_timing_scan(d_in, nframes, c->prm.frame_size, c->d_taps, (int32_t *)c->index.p, nullptr,
+                                          c->d_status, c->stream));
+            *d_index_out = (const int32_t *)c->index.p;
+            return QPSK_OK;
+        }
         const size_t bytes = sizeof(float) * 2 * (size_t)nframes * c->prm.frame_size;
         rc = ensure(c, c->filtered, bytes);
         if (rc) return rc;
         KERNEL_TRY(launch_rrc_fir(d_in, nullptr, (float *)c->filtered.p, c->d_taps, nframes, c->prm.frame_size, c->stream));
         KERNEL_TRY(launch_timing_hist((const float *)c->filtered.p, nframes, c->prm.frame_size, c->cycles,
-                                      (int32_t *)c->index.p, nullptr, tuned(c->tune.hist_generic, 0) != 0, c->stream));
+                                      (int32_t *)c->index.p, nullptr, tuned(c->tune.hist_generic, 0) == 2, c->stream));
         *d_index_out = (const int32_t *)c->index.p;
         return QPSK_OK;
     }
@@ -660,7 +676,19 @@ int qpsk_timing_hist_batch(qpsk_ctx *c, const float *d_filtered, int nframes, in
     if (nframes <= 0) return fail(QPSK_ERR_ARG, "nframes = %d", nframes);
     if (bind(c)) return QPSK_ERR_HIP;
     KERNEL_TRY(launch_timing_hist(d_filtered, nframes, c->prm.frame_size, c->cycles, d_index, d_hist,
-                                  tuned(c->tune.hist_generic, 0) != 0, c->stream));
+                                  tuned(c->tune.hist_generic, 0) == 2, c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_timing_scan_batch(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index, int32_t *d_hist)
+{
+    if (!c || !d_in || !d_index) return fail(QPSK_ERR_ARG, "qpsk_timing_scan_batch: null argument");
+    if (nframes <= 0) return fail(QPSK_ERR_ARG, "nframes = %d", nframes);
+    if (bind(c)) return QPSK_ERR_HIP;
+    if (!(c->cycles == 8 && c->prm.frame_size % timing_scan_tile() == 0 && ((uintptr_t)d_in % 16) == 0))
+        return fail(QPSK_ERR_ARG, "qpsk_timing_scan_batch needs CYCLES = 8, frame_size %% %d == 0 and 16-byte aligned input "
+                                  "(use qpsk_rrc_fir_batch + qpsk_timing_hist_batch otherwise)", timing_scan_tile());
+    KERNEL_TRY(launch_timing_scan(d_in, nframes, c->prm.frame_size, c->d_taps, d_index, d_hist, c->d_status, c->stream));
     return QPSK_OK;
 }
 
@@ -783,7 +811,7 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
     KERNEL_TRY(launch_delay_line(d_in, c->s_memory, n, L, c->stream));
     /* qpsk.c:127-180 */
     if (c->prm.timing_mode == QPSK_TIMING_HIST)
-        KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, nullptr, tuned(c->tune.hist_generic, 0) != 0, c->stream));
+        KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, nullptr, tuned(c->tune.hist_generic, 0) == 2, c->stream));
     else if (c->prm.timing_mode == QPSK_TIMING_FIXED)
         KERNEL_TRY(launch_fill_i32(idx, n, c->prm.fixed_index, c->stream));
     else if (int rf = fft_timing_indices(c, d_in, n, idx))   /* stateless: it looks at the raw block from sample 2 on */

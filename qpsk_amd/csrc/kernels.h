@@ -89,6 +89,12 @@ int fft_lds_max_n(void);
 int fft_big_block(void);
 int launch_fft_big(const double *in, double *out, const double *twb, const double *twn, int nbatch, int n, int log2n,
                    int inverse, hipStream_t s);   /* larger powers of two, two passes; in != out */
+/* timing_scan.hip: full-rate FIR + histogram scan fused through LDS (CYCLES = 8, frame_size % timing_scan_tile() == 0) */
+size_t timing_scan_lds_bytes(void);
+int timing_scan_tile(void);
+int prepare_timing_scan(void);
+int launch_timing_scan(const float *x, int nframes, int frame_size, const float *taps, int32_t *index, int32_t *hist,
+                       int *status, hipStream_t s);
 /* timing_fft.hip */
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
                       const double *cs, int32_t *index, float *yout, double *Xout, hipStream_t s);   /* yout [nframes][512][2],

@@ -46,7 +46,7 @@ API_SYMBOLS = [
     "qpsk_last_error", "qpsk_version", "qpsk_device_count", "qpsk_params_default", "qpsk_ctx_create",
     "qpsk_ctx_destroy", "qpsk_ctx_sync", "qpsk_ctx_set_stream", "qpsk_ctx_set_tuning", "qpsk_ctx_cycles", "qpsk_ctx_nsym",
     "qpsk_ctx_get_taps", "qpsk_ctx_get_gains", "qpsk_ctx_set_taps", "qpsk_ctx_set_loop", "qpsk_rx_batch",
-    "qpsk_rx_batch_bw", "qpsk_rrc_fir_batch", "qpsk_timing_hist_batch", "qpsk_timing_fft_batch", "qpsk_costas_batch", "qpsk_fft_batch",
+    "qpsk_rx_batch_bw", "qpsk_rrc_fir_batch", "qpsk_timing_hist_batch", "qpsk_timing_scan_batch", "qpsk_timing_fft_batch", "qpsk_costas_batch", "qpsk_fft_batch",
     "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
     "qpsk_streams_rx_pcm", "qpsk_streams_rx_pcm_host", "qpsk_dev_alloc", "qpsk_dev_free", "qpsk_dev_upload", "qpsk_dev_download",
     "qpsk_selftest_sincos_hash", "qpsk_crc16_batch", "qpsk_interleave_batch", "qpsk_scramble_batch",
@@ -102,6 +102,7 @@ def load():
     L.qpsk_rrc_fir_batch.argtypes = [vp, vp, vp, vp, i32, i32]
     L.qpsk_timing_hist_batch.argtypes = [vp, vp, i32, vp, vp]
     L.qpsk_timing_fft_batch.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.qpsk_timing_scan_batch.argtypes = [vp, vp, i32, vp, vp]
     L.qpsk_costas_batch.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.qpsk_fft_batch.argtypes = [vp, vp, vp, i32, i32, i32]
     L.qpsk_streams_reset.argtypes = [vp, i32, C.c_double]
@@ -260,6 +261,15 @@ class Modem:
         hist = self.empty((y.shape[0], 8), t.int32) if want_hist else None
         self._check(self.L.qpsk_timing_hist_batch(self.h, _ptr(y), y.shape[0], _ptr(idx), _ptr(hist)))
         return (idx, hist) if want_hist else idx
+
+    def timing_scan(self, frames):
+        """histogram timing estimate straight from unfiltered (F, frame_size, 2) frames -> (index (F,), hist (F, 8))"""
+        t = self.torch
+        x = self._dev(frames, t.float32)
+        idx = self.empty((x.shape[0],), t.int32)
+        hist = self.empty((x.shape[0], 8), t.int32)
+        self._check(self.L.qpsk_timing_scan_batch(self.h, _ptr(x), x.shape[0], _ptr(idx), _ptr(hist)))
+        return idx, hist
 
     def timing_fft(self, frames, want_internals=False):
         """FFT timing estimate of (F, frame_size, 2) frames -> index (F,) [, filtered (F, 512, 2), spectrum (F, 512) complex128]"""

@@ -443,7 +443,7 @@ def test_timing_histogram(oracle, cycles, L, generic):
     rs = 2400.0
     m = modem(fs=rs * cycles, rs=rs, frame_size=L)
     if generic:
-        m.tune(hist_generic=1)
+        m.tune(hist_generic=2)
     x, _ = make_frames(37, L, cycles, m.taps, rs * cycles, noise=0.1, base_seed=cycles)
     x[0] = 0.0
     x[1] = random_frames(1, L, seed=5)[0]
@@ -852,3 +852,39 @@ def test_full_size_config3_properties(oracle):
     for k in ("sym", "phase", "freq", "index"):
         assert bits_equal(cpu(a[k])[pick], want[k].astype(cpu(a[k]).dtype)), k
     assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
+
+
+# ------------------------------------------------------------------ histogram timing without a filtered block in memory
+@pytest.mark.parametrize("L,F", [(256, 5), (1024, 37), (16384, 33)])
+def test_timing_scan_fused(oracle, L, F):
+    """qpsk_timing_scan_batch (full-rate FIR + amplitude-histogram scan fused through LDS, what QPSK_TIMING_HIST runs
+    on): index AND every histogram bin equal the two-kernel composition rrc_fir -> timing_hist (itself pinned to the
+    reference's fixtures) and the oracle; frame counts ragged against the 16-frame workgroups"""
+    fs, rs = 19200.0, 2400.0
+    m = modem(fs=fs, rs=rs, frame_size=L)
+    x, _ = make_frames(F, L, 8, m.taps, fs, noise=0.1, base_seed=L)
+    x[0] = 0.0
+    x[1] = random_frames(1, L, seed=5)[0]
+    x[2] = np.abs(random_frames(1, L, seed=6)[0]) * np.linspace(0.01, 3.0, L)[:, None]     # the running max keeps moving
+    if F > 4:
+        x[3, L // 2:] = 0.0
+    idx, hist = m.timing_scan(x)
+    m.sync()
+    idx2, hist2 = m.timing_hist(m.rrc_fir(x), want_hist=True)
+    m.sync()
+    assert np.array_equal(cpu(idx), cpu(idx2)) and np.array_equal(cpu(hist), cpu(hist2))
+    taps = oracle.rrc_make(fs, rs, np.float32(.35))
+    for f in range(F):
+        y = x[f].copy()
+        oracle.rrc_fir(taps, np.zeros((127, 2), np.float32), y)
+        assert cpu(idx)[f] == oracle.timing_index(y, 8), f
+    # the three-kernel path (QPSK_HIST_GENERIC = 1) and the fused one give the same batch results
+    mh = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_HIST)
+    a = mh.rx_batch(x, want_costas=True)
+    mh.sync()
+    mh.tune(hist_generic=1)
+    b = mh.rx_batch(x, want_costas=True)
+    mh.sync()
+    for k in ("sym", "costas", "phase", "freq", "index", "hz"):
+        assert bits_equal(cpu(a[k]), cpu(b[k])), k
+    assert np.array_equal(cpu(a["index"]), cpu(idx))

@@ -3,8 +3,9 @@
 (R = 2 or 4 consecutive decimated outputs per lane) as ONE hand-scheduled gfx950 instruction stream (rrc_fir.c:22-26
 evaluated at the decimated outputs a lane owns).
 
-    python tools/gen_fir_asm.py 1 100 2 > qpsk_amd/csrc/fir_r2_asm.h      # depth, first VGPR, R
-    python tools/gen_fir_asm.py 1 168 4 > qpsk_amd/csrc/fir_r4_asm.h
+    python tools/gen_fir_asm.py 1 100 2 > qpsk_amd/csrc/fir_r2_asm.h      # depth, first VGPR, R [, step]
+    python tools/gen_fir_asm.py 1 144 4 > qpsk_amd/csrc/fir_r4_asm.h
+    python tools/gen_fir_asm.py 1 144 8 1 > qpsk_amd/csrc/fir_full8_asm.h  # full rate: 8 CONSECUTIVE outputs per lane
 
 Why a generated stream and not C++: the compiler's version of the same sum (asm-pinned product/add order) carries
 ~60 v_mov and ~60 s_nop per 508 packed multiply/adds, and fetches LDS only one block of 8 window positions ahead --
@@ -24,11 +25,14 @@ import sys
 NTAPS, C = 127, 8
 DEPTH = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 V0 = int(sys.argv[2]) if len(sys.argv) > 2 else 76   # first VGPR of the block's fixed registers (even)
-R = int(sys.argv[3]) if len(sys.argv) > 3 else 2     # symbols per lane
-TSTEPS = NTAPS + C * (R - 1)          # 135 (R = 2) or 151 (R = 4) window positions
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 2     # outputs per lane
+STEP = int(sys.argv[4]) if len(sys.argv) > 4 else C  # samples between a lane's outputs: CYCLES (decimated) or 1 (full rate)
+TSTEPS = NTAPS + STEP * (R - 1)       # window positions a lane sweeps: 135 (R = 2), 151 (R = 4), 134 (full rate, R = 8)
 NB = (TSTEPS + C - 1) // C            # blocks of 8 positions
-NW, NG = DEPTH + 1, DEPTH + R         # live window blocks / tap groups (symbol r reaches back r groups)
-PAD = R * C                           # lanes are PAD positions apart: position p at slot p + 2*(p/PAD)
+REACH = (STEP * (R - 1) + C - 1) // C # tap groups an output reaches back behind the block's own
+NW, NG = DEPTH + 1, DEPTH + 1 + REACH # live window blocks / tap groups
+PAD = R * STEP                        # lanes are PAD positions apart: position p at slot p + 2*(p/PAD)
+NAME = "fir_r%d" % R if STEP == C else "fir_full%d" % R
 
 W0 = V0                               # window blocks: NW x 16 dwords
 T0 = W0 + 16 * NW                     # tap groups:    NG x 8 dwords
@@ -92,7 +96,7 @@ def main():
                 if t >= TSTEPS:
                     continue
                 for sym in range(R):
-                    k = t - C * sym
+                    k = t - STEP * sym
                     if 0 <= k < NTAPS:
                         treg, sel = tap_operand(k)
                         p = "v[%d:%d]" % (P0 + 2 * np_, P0 + 2 * np_ + 1)
@@ -108,26 +112,26 @@ def main():
     outs = ", ".join('[a%d] "=&v"(a%d)' % (r, r) for r in range(R))
     copy = "\n".join("    acc%d = a%d;" % (r, r) for r in range(R))
     print('''/*
- * fir_r%(R)d_asm.h -- GENERATED by tools/gen_fir_asm.py %(D)d %(V0)d %(R)d; do not edit.
+ * %(NAME)s_asm.h -- GENERATED by tools/gen_fir_asm.py %(D)d %(V0)d %(R)d %(STEP)d; do not edit.
  *
- * The RRC FIR step of a FIR wave with %(R)d consecutive decimated outputs per lane (rrc_fir.c:22-26 at those
+ * The RRC FIR step of a FIR wave with %(R)d outputs per lane, %(STEP)d sample(s) apart (rrc_fir.c:22-26 at those
  * outputs) as one hand-scheduled gfx950 instruction stream: %(nmul)d packed multiplies and as many packed adds,
  * unfused, taps 0..126 in order into one (re, im) accumulator per symbol; window pairs (one aligned 16-byte word
  * per two positions: position p at slot p + 2 (p / %(PAD)d) from the lane's base) and tap groups fetched from LDS
  * %(D)d block(s) of 8 positions ahead (counted lgkmcnt waits), no register moves, no nops.  See the generator.
  * Fixed registers v%(V0)d..v%(VL)d are scratch owned by the block.
  */
-#ifndef QPSK_FIR_R%(R)d_ASM_H
-#define QPSK_FIR_R%(R)d_ASM_H
+#ifndef QPSK_%(UNAME)s_ASM_H
+#define QPSK_%(UNAME)s_ASM_H
 
 #include "qpsk_device.h"
 
 namespace qpsk {
 
-constexpr int FIR_R%(R)d_ASM_FIRST_VGPR = %(V0)d, FIR_R%(R)d_ASM_END_VGPR = %(VEND)d;
+constexpr int %(UNAME)s_ASM_FIRST_VGPR = %(V0)d, %(UNAME)s_ASM_END_VGPR = %(VEND)d;
 
 /* rd_addr: LDS byte address of the lane's window position 0; tap_addr: LDS byte address of the 128 taps */
-__device__ __forceinline__ void fir_r%(R)d_asm(unsigned rd_addr, unsigned tap_addr, %(args)s)
+__device__ __forceinline__ void %(NAME)s_asm(unsigned rd_addr, unsigned tap_addr, %(args)s)
 {
     v2f %(decl)s;
     asm volatile(
@@ -140,7 +144,7 @@ __device__ __forceinline__ void fir_r%(R)d_asm(unsigned rd_addr, unsigned tap_ad
 }
 
 } // namespace qpsk
-#endif''' % dict(R=R, D=DEPTH, V0=V0, VL=VEND - 1, VEND=VEND, nmul=nmul, PAD=PAD, args=args, decl=decl, body=body, outs=outs,
+#endif''' % dict(NAME=NAME, UNAME=NAME.upper(), STEP=STEP, R=R, D=DEPTH, V0=V0, VL=VEND - 1, VEND=VEND, nmul=nmul, PAD=PAD, args=args, decl=decl, body=body, outs=outs,
                   clob=clob, copy=copy))
 
 
