@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Sum rocprofv3 --pmc counter rows per kernel over the gpurun_out/hist_* passes of tools/measure_hist.sh and print
+per-launch values (counter values of a kernel are summed over its dispatches' rows and divided by its dispatches)."""
+import csv
+import glob
+import collections
+import sys
+
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(lambda: collections.defaultdict(set))
+for p in glob.glob((sys.argv[1] if len(sys.argv) > 1 else "gpurun_out") + "/hist_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "qpsk" not in k:
+            continue
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+for k in sorted(tot):
+    print(k)
+    for c in sorted(tot[k]):
+        n = len(disp[k][c])
+        print("  %-24s %14.4g per launch (%d launches)" % (c, tot[k][c] / n, n))

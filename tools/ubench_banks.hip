@@ -72,8 +72,36 @@ static void run(const char *name, int per_iter, int waves)
     CHECK(hipFree(cyc));
 }
 
-int main()
+// (3) what s_memtime counts and what the shader clock is under load: counter ticks of workgroup 0 / wave 0 against the
+// kernel's HIP-event time, for one workgroup alone and for the whole chip running the packed stream
+static void clock_test(int grid)
 {
+    unsigned long long *cyc;
+    CHECK(hipMalloc(&cyc, 8 * 16));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int iters = 20000;
+    hipLaunchKernelGGL(bench<0>, dim3(grid), dim3(1024), 0, 0, cyc, 200);
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(bench<0>, dim3(grid), dim3(1024), 0, 0, cyc, iters);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[16], mx = 0;
+    CHECK(hipMemcpy(h, cyc, 8 * 16, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; i++) mx = h[i] > mx ? h[i] : mx;
+    printf("clock: %4d workgroups x 16 waves of pk_mul: %.3f ms by events, %llu s_memtime ticks in the slowest wave -> %.1f ticks/us; %.2f ticks per instruction and SIMD\n",
+           grid, ms, mx, (double)mx / (ms * 1e3), (double)mx / ((double)iters * 128) / 4.0);
+    CHECK(hipFree(cyc));
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) {
+        for (int g : {1, 64, 256, 512}) clock_test(g);
+        return 0;
+    }
     for (int w : {1, 8, 12, 16}) {      // 8 waves = two per SIMD, 12 = three, 16 = four
         run<0>("pk_mul tap-broadcast(lo), tap and window in the SAME banks", 128, w);
         run<1>("pk_mul tap-broadcast(lo), tap and window in DIFFERENT banks", 128, w);
