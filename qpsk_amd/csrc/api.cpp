@@ -82,7 +82,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
 #ifdef QPSK_PIPE_PROFILE
 static const int PIPE_VARIANT_MASK = ~0;
 #else
-static const int PIPE_VARIANT_MASK = 4 | 8 | 64 | 128 | 256 | 512 | 1024;
+static const int PIPE_VARIANT_MASK = 4 | 8 | 16 | 64 | 128 | 256 | 512 | 1024;
 #endif
 
 struct qpsk_ctx {

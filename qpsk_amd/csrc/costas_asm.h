@@ -166,11 +166,12 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
  * write of the step before (steps 0, 4, 8, 12) or none (steps 2, 6, 10, 14) */
 #define QPSK_WAIT0 "s_waitcnt lgkmcnt(0)\n\t"
 #define QPSK_WAIT1 "s_waitcnt lgkmcnt(1)\n\t"
-#define QPSK_RDA(OFF) "ds_read_b128 v[120:123], %[da] offset:" QPSK_STR(OFF) "\n\t"
-#define QPSK_RDB(OFF) "ds_read_b128 v[136:139], %[da] offset:" QPSK_STR(OFF) "\n\t"
+/* QPSK_DA / QPSK_ZA: the registers holding the group's symbol / record address (defined in front of each stream) */
+#define QPSK_RDA(OFF) "ds_read_b128 v[120:123], " QPSK_DA " offset:" QPSK_STR(OFF) "\n\t"
+#define QPSK_RDB(OFF) "ds_read_b128 v[136:139], " QPSK_DA " offset:" QPSK_STR(OFF) "\n\t"
 /* the records of four steps, their starting phases v140..v143, in one write (issued by the fourth of them once its
  * own phase has been through the 2*pi test, before its update overwrites v140) */
-#define QPSK_QW(OFF) "ds_write_b128 %[za], v[140:143] offset:" QPSK_STR(OFF) "\n\t"
+#define QPSK_QW(OFF) "ds_write_b128 " QPSK_ZA ", v[140:143] offset:" QPSK_STR(OFF) "\n\t"
 
 /* four steps k = 4m .. 4m+3 (k > 0): the phase of step k lives in v140 + k % 4, the clamped frequency in v133
  * (odd k) or v135 (even k); SA/SB = the symbol sets of the first and the second pair, RD1/RD2 the fetches of the
@@ -191,6 +192,8 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
  * groups NOT done: 0, or -- if the flag word is nonzero -- the abandoned group and everything after it, with
  * phase/freq restored to that group's start.  freq must not be -0.0f (see the header).
  */
+#define QPSK_DA "%[da]"
+#define QPSK_ZA "%[za]"
 __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, unsigned &d_addr, unsigned &z_addr,
                                                    unsigned groups, float alpha, float beta, float min_freq,
                                                    float max_freq, unsigned long long &flags_out)
@@ -272,6 +275,141 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
     flags_out = flags;
     return groups;
 }
+
+#undef QPSK_DA
+#undef QPSK_ZA
+
+/*
+ * The same stream running THROUGH the chunk hand-overs of the pipeline kernels' rings (rx_fused.hip): symbol ring and
+ * record ring of 128 symbols = 8 groups per lane (two 64-symbol chunks), group k at ring position k % 8.  What the
+ * serial wave did between two costas_asm_run() calls per chunk -- ready[] poll, acquire, address set-up, an exposed
+ * LDS read of the first symbol pair, waiting out the last record write, release, consumed -- cost ~0.5-0.7 k cycles
+ * per chunk, every cycle of it on the kernel's critical path (config 2 sits on this wave).  Here:
+ *   - every group reads the lane's producer counter ready[] (one 4-byte LDS read per 16 steps, in the shadow of the
+ *     steps); at a chunk boundary the value read at the START of the chunk's last group decides: LDS operations of
+ *     a wave execute in order, so everything read after a counter read that showed the next chunk is that chunk
+ *     -- including the usual fetch of the next group's first symbol pair two steps before the group ends;
+ *   - consumed = chunk + 1 is one LDS write by lane 0 behind the chunk's last record write (same order argument:
+ *     the FIR waves read the counter, then the records);
+ *   - the stream stops at a boundary whose next chunk was not yet there (the caller waits, comes back), at kend,
+ *     or inside a group it abandons (as costas_asm_run: state restored, caller redoes that group).
+ * k (in/out): absolute group number, a multiple of 4 on entry unless the caller resumes behind a group it redid.
+ * Registers: as costas_asm_run, plus v132 / v134 / v124 = symbol address, record address, address of the next
+ * group's first symbol pair, v125 = the counter read.
+ */
+#define QPSK_DA "v132"
+#define QPSK_ZA "v134"
+#define QPSK_RDN "ds_read_b128 v[120:123], v124\n\t"
+__device__ __forceinline__ void costas_asm_run_ring(float &phase, float &freq, unsigned d_base, unsigned z_base,
+                                                    unsigned ready_addr, unsigned consumed_addr, unsigned &k, unsigned kend,
+                                                    float alpha, float beta, float min_freq, float max_freq,
+                                                    unsigned long long &flags_out)
+{
+    unsigned long long flags, tmp, ex;
+    unsigned t0, t1;
+    const double magic = 0x1.8p52, c3 = -0x1.6c087e89a359dp-10, s2 = 0x1.1107605230bc4p-7;
+    double beal;
+    {
+        const float2 ba = make_float2(beta, alpha);
+        __builtin_memcpy(&beal, &ba, 8);
+    }
+    asm volatile(
+        "v_mov_b32 v128, 0x54442d18\n\t"        /* 2*pi = 0x401921FB54442D18 */
+        "v_mov_b32 v127, 0x401921fb\n\t"
+        "s_and_b32 %[t0], %[k], 7\n\t"
+        "s_lshl_b32 %[t0], %[t0], 7\n\t"
+        "v_add_u32_e32 v132, %[t0], %[db]\n\t"
+        "ds_read_b128 v[120:123], v132\n\t"
+        "s_mov_b64 %[fl], 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        "2:\n\t"
+        /* ring addresses of group k and of group k + 1's first pair; the producer counter */
+        "s_and_b32 %[t0], %[k], 7\n\t"
+        "s_lshl_b32 %[t1], %[t0], 7\n\t"
+        "v_add_u32_e32 v132, %[t1], %[db]\n\t"
+        "s_lshl_b32 %[t1], %[t0], 6\n\t"
+        "v_add_u32_e32 v134, %[t1], %[zb]\n\t"
+        "s_add_u32 %[t0], %[k], 1\n\t"
+        "s_and_b32 %[t0], %[t0], 7\n\t"
+        "s_lshl_b32 %[t0], %[t0], 7\n\t"
+        "v_add_u32_e32 v124, %[t0], %[db]\n\t"
+        "ds_read_b32 v125, %[ra]\n\t"
+        "v_mov_b32 v130, %[p]\n\t"
+        "v_mov_b32 v131, %[f]\n\t"
+        "v_mov_b32 v126, 0x7f800000\n\t"
+        "v_mov_b32 v140, %[p]\n\t"
+        /* steps 0..3; outstanding in front of the first pair's use: the last group's record write and the counter read */
+        QPSK_HEAD_CHAIN("v140")
+        QPSK_BODY("v140", "%[f]", "v141", "v[120:121]", "s_waitcnt lgkmcnt(2)\n\t", QPSK_RDB(16), "")
+        QPSK_HEAD_DEFERRED("v141", "v133", "101", "201")
+        QPSK_BODY("v141", "v133", "v142", "v[122:123]", "", "", "")
+        QPSK_HEAD_DEFERRED("v142", "v135", "102", "202")
+        QPSK_BODY("v142", "v135", "v143", "v[136:137]", QPSK_WAIT0, QPSK_RDA(32), "")
+        QPSK_HEAD_DEFERRED("v143", "v133", "103", "203")
+        QPSK_BODY("v143", "v133", "v140", "v[138:139]", "", "", QPSK_QW(0))
+        QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(48), QPSK_RDA(64), 16, "v140", "04", "05", "06", "07")
+        QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(80), QPSK_RDA(96), 32, "v140", "08", "09", "10", "11")
+        QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(112), QPSK_RDN, 48, "%[p]", "12", "13", "14", "15")
+        QPSK_TAIL("%[p]", "%[f]", "116", "216")
+        "v_cmp_eq_f32_e64 %[tm], 0, v126\n\t"
+        "s_or_b64 %[fl], %[fl], %[tm]\n\t"
+        "s_cmp_lg_u64 %[fl], 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_add_u32 %[k], %[k], 1\n\t"
+        "s_and_b32 %[t0], %[k], 3\n\t"
+        "s_cmp_lg_u32 %[t0], 0\n\t"
+        "s_cbranch_scc1 2b\n\t"                 /* inside a chunk (kend is a multiple of 4) */
+        /* chunk k / 4 - 1 is done: consumed = k / 4, by lane 0, behind the record writes */
+        "s_lshr_b32 %[t0], %[k], 2\n\t"
+        "v_mov_b32 v104, %[t0]\n\t"
+        "s_mov_b64 %[ex], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "ds_write_b32 %[ca], v104\n\t"
+        "s_mov_b64 exec, %[ex]\n\t"
+        "s_cmp_ge_u32 %[k], %[ke]\n\t"
+        "s_cbranch_scc1 4f\n\t"
+        /* next chunk there?  ready[] >= k / 4 + 1 in every lane, as read at the start of the group just done */
+        "v_cmp_le_i32_e64 %[tm], v125, %[t0]\n\t"
+        "s_cmp_lg_u64 %[tm], 0\n\t"
+        "s_cbranch_scc0 2b\n\t"
+        "s_branch 4f\n"
+        "3:\n\t"
+        "v_mov_b32 %[p], v130\n\t"
+        "v_mov_b32 %[f], v131\n\t"
+        "s_branch 4f\n"
+        QPSK_WRAP_HEAD("v141", "101", "201")
+        QPSK_WRAP_HEAD("v142", "102", "202")
+        QPSK_WRAP_HEAD("v143", "103", "203")
+        QPSK_WRAP_HEAD("v140", "104", "204")
+        QPSK_WRAP_HEAD("v141", "105", "205")
+        QPSK_WRAP_HEAD("v142", "106", "206")
+        QPSK_WRAP_HEAD("v143", "107", "207")
+        QPSK_WRAP_HEAD("v140", "108", "208")
+        QPSK_WRAP_HEAD("v141", "109", "209")
+        QPSK_WRAP_HEAD("v142", "110", "210")
+        QPSK_WRAP_HEAD("v143", "111", "211")
+        QPSK_WRAP_HEAD("v140", "112", "212")
+        QPSK_WRAP_HEAD("v141", "113", "213")
+        QPSK_WRAP_HEAD("v142", "114", "214")
+        QPSK_WRAP_HEAD("v143", "115", "215")
+        QPSK_WRAP_TAIL("%[p]", "116", "216")
+        "4:\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [p] "+v"(phase), [f] "+v"(freq), [k] "+s"(k), [fl] "=&s"(flags), [tm] "=&s"(tmp), [ex] "=&s"(ex),
+          [t0] "=&s"(t0), [t1] "=&s"(t1)
+        : [db] "v"(d_base), [zb] "v"(z_base), [ra] "v"(ready_addr), [ca] "v"(consumed_addr), [ke] "s"(kend),
+          [magic] "v"(magic), [c3] "v"(c3), [s2] "v"(s2), [fmax] "v"(max_freq), [beal] "v"(beal),
+          [k2pi] "s"(0x1.45F306DC9C883p-1), [hpi] "s"(0x1.921FB54442D18p0), [c4] "s"(0x1.99343027bf8c3p-16),
+          [s3] "s"(-0x1.994eb3774cf24p-13), [c2] "s"(0x1.55553e1068f19p-5), [s1] "s"(-0x1.555545995a603p-3),
+          [c1] "s"(-0x1.ffffffd0c621cp-2), [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+          "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
+          "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135",
+          "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143");
+    flags_out = flags;
+}
+#undef QPSK_DA
+#undef QPSK_ZA
 
 } // namespace qpsk
 #endif

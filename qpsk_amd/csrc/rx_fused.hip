@@ -219,7 +219,50 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
     unsigned long long dummy = 0;
     ctick(dummy);
 #endif
+    /* full chunks behind the first go through the stream that runs across the ring hand-overs (costas_asm.h,
+     * costas_asm_run_ring); the first chunk (loaded state, 4-symbol alignment of the stream), a last partial one and
+     * the variants below stay chunk by chunk */
+#ifdef QPSK_PIPE_PROFILE
+    const bool ring_stream = fast_clamp && !(a.dbg & (2 | 8 | 16 | 32)) && S == 4 * COSTAS_ASM_GROUP && DR == 2;
+#else
+    const bool ring_stream = fast_clamp && !(a.dbg & (8 | 16)) && S == 4 * COSTAS_ASM_GROUP && DR == 2;
+#endif
     for (int c = 0; c < nchunks && ok; c++) {
+        if (ring_stream && c >= 1 && (c + 1) * S <= N) {
+            const int cfull = N / S;      /* chunks c .. cfull - 1 are whole */
+            if (active) {
+                constexpr int AG = COSTAS_ASM_GROUP;
+                unsigned k = 4u * (unsigned)c;
+                const unsigned kend = 4u * (unsigned)cfull;
+                const unsigned d_base = lds_addr(dl), z_base = lds_addr(zl);
+                const unsigned ready_addr = lds_addr(&sm->ready[gw]), consumed_addr = lds_addr(&sm->consumed);
+                while (k < kend) {
+                    if ((k & 3u) == 0u) {     /* entering a chunk: the stream left because it was not there yet (or this is the start) */
+                        ok = wait_ge(&sm->ready[gw], (int)(k >> 2) + 1, &sm->abort_flag);
+                        if (!__all(ok)) { ok = false; break; }
+                    }
+                    unsigned long long fl = 1;
+                    if (!__any(__float_as_uint(fr) == 0x80000000u)) {
+                        unsigned ks = __builtin_amdgcn_readfirstlane(k);
+                        costas_asm_run_ring(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kend, al, be, fmin_, fmax_, fl);
+                        k = ks;
+                    }
+                    if (fl != 0 && k < kend) {      /* group k abandoned (or never started): the C++ step, then on */
+                        const int at = (int)(k & 7u) * AG;
+                        for (int i = 0; i < AG; i++) {
+                            float tx, ty; unsigned qq;
+                            zl[at + i] = ph;
+                            costas_step_t<true>(ph, fr, al, be, fmin_, fmax_, dl[at + i], tx, ty, qq, over);
+                        }
+                        k++;
+                        if ((k & 3u) == 0u && lane == 0) st_release(&sm->consumed, (int)(k >> 2));
+                    }
+                }
+            }
+            ok = __all(ok);
+            c = cfull - 1;
+            continue;
+        }
         ok = wait_ge(&sm->ready[gw], c + 1, &sm->abort_flag);
         if (!__all(ok)) { ok = false; break; }
 #ifdef QPSK_PIPE_PROFILE
