@@ -524,6 +524,73 @@ def test_costas_zero_error_and_signed_zero_state(oracle):
         assert bits_equal(cpu(st[f]), np.array([c.phase, c.freq], np.float32)), (f, cpu(st[f]), c.phase, c.freq)
 
 
+def test_stream_across_ring_handovers_takes_its_fallbacks(oracle):
+    """the Costas stream that runs across the chunk hand-overs (costas_asm_run_ring) abandons a group that meets an
+    exact-zero detector input and the C++ step redoes it -- wherever in a 64-symbol chunk the group sits (first, inner,
+    last: the last one also owes the `consumed` hand-over), also several in a row and whole zero chunks; a frame whose
+    symbol count is not a whole number of chunks ends chunk by chunk.  Both forms (QPSK_PIPE_DBG=16: chunk by chunk
+    everywhere) must give the oracle's bits."""
+    import torch
+    from oracle.pyoracle import Costas
+    rng = np.random.default_rng(23)
+    for N in (512, 456):
+        m = modem(fs=19200.0, rs=2400.0, frame_size=N * 8)
+        F = 20
+        d = rng.standard_normal((F, N, 2)).astype(np.float32)
+        zero_at = {0: [64], 1: [79], 2: [112], 3: [127], 4: [128, 191, 192], 5: list(range(176, 208)), 6: list(range(192, 320)),
+                   7: [255, 256, 257], 8: [N - 1], 9: [N - 17], 10: list(range(64, N)), 11: [100, 200, 300, 400]}
+        for f, where in zero_at.items():
+            d[f, where] = 0.0
+        d[12, 130] = (1.5, -1.5)          # |T.x| == |T.y| needs phase 0: not here; a plain diagonal symbol instead
+        d[13] *= 1e-20                    # tiny but nonzero: no fallback
+        st0 = np.zeros((F, 2), np.float32)
+        st0[14] = [-0.0, -0.0]
+        st0[15] = [3.0, 0.9]              # wraps every few steps
+        st0[16] = [-6.2, -0.99]
+        for dbg in (0, 16):
+            m.tune(pipe_dbg=dbg)
+            st = torch.from_numpy(st0.copy()).cuda()
+            sym, z = m.costas(d, st)
+            m.sync()
+            for f in range(F):
+                c = Costas()
+                oracle.lib.qo_costas_create(C.byref(c), BW, -1.0, 1.0)
+                c.phase, c.freq = float(st0[f, 0]), float(st0[f, 1])
+                zr, zi = C.c_float(), C.c_float()
+                want = np.empty((N, 2), np.float32)
+                wsym = np.empty(N, np.uint8)
+                for i in range(N):
+                    wsym[i] = oracle.lib.qo_costas_step(C.byref(c), float(d[f, i, 0]), float(d[f, i, 1]), C.byref(zr), C.byref(zi))
+                    want[i] = zr.value, zi.value
+                assert np.array_equal(cpu(sym[f]), wsym), (N, dbg, f)
+                assert bits_equal(cpu(z[f]), want), (N, dbg, f)
+                assert bits_equal(cpu(st[f]), np.array([c.phase, c.freq], np.float32)), (N, dbg, f)
+
+
+@pytest.mark.parametrize("pipe_v,G", [(1, None), (2, 32), (2, 5)])
+def test_zero_runs_inside_frames_both_pipeline_kernels(oracle, pipe_v, G):
+    """silence inside a frame (runs of zero samples longer than the filter) gives exact-zero symbols in the middle of
+    the rings' chunks: the receive kernels' serial wave leaves its stream there and comes back, per frame at different
+    places, while the other frames of the workgroup carry on"""
+    fs, rs, L, F = 19200.0, 2400.0, 8192, 40
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=77, noise=0.02)
+    rng = np.random.default_rng(5)
+    for f in range(0, F, 2):
+        for _ in range(1 + f % 3):
+            a = int(rng.integers(0, L - 200))
+            x[f, a:a + int(rng.integers(140, 1500))] = 0.0
+    x[3, 512 * 3 - 130:512 * 5] = 0.0        # zero symbols exactly from a chunk boundary on
+    x[5, :4096] = 0.0
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=6, want_costas=True)
+    m.tune(pipe_v=pipe_v, pipe_g=G)
+    for dbg in (0, 16):
+        m.tune(pipe_dbg=dbg)
+        got = m.rx_batch(x, want_costas=True)
+        m.sync()
+        assert_batch_equal(got, want)
+
+
 def test_fft_batch(oracle):
     rng = np.random.default_rng(4)
     m = modem()
