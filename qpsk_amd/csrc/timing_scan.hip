@@ -31,6 +31,10 @@
 #include "qpsk_device.h"
 #include "costas_asm.h"      /* lds_addr() */
 #include "fir_full8_asm.h"
+#ifdef QPSK_TSCAN_NOLDS      /* timing experiment only (tools): the filter stream without its LDS reads */
+#include "../../build_ubench/fir_full8_nolds_asm.h"
+#define fir_full8_asm fir_full8_nolds_asm
+#endif
 #include "kernels.h"
 
 namespace qpsk {
@@ -178,7 +182,36 @@ timing_scan_kernel(const float2 *__restrict__ x, int nframes, int frame_size, co
     };
     prefetch(0);
     bool ok = true;
+#ifdef QPSK_PIPE_PROFILE
+    /* measurement build: where FIR wave w of workgroup 0 spends its cycles (printed per tile) */
+    const bool prof = blockIdx.x == 0 && hist_out == nullptr && (nframes & 1) == 1;
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = 0;
+    auto tick = [&](int k) {
+        if (prof) {
+            unsigned long long tt;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+            if (k >= 0) tacc[k] += tt - tlast;
+            tlast = tt;
+        }
+    };
+    tick(-1);
+#else
+    auto tick = [](int) {};
+#endif
     for (int t = 0; t < ntiles && ok; t++) {
+        /* The two FIR waves of a SIMD (w and w ^ 4) are served oldest first: left alone, the older one runs at nearly
+         * full rate, finishes its two frames after ~55 % of the kernel and leaves the younger one to run the rest
+         * alone at a lone wave's rate (every LDS instruction's latency exposed) [measured: 13.5 k against 25 k
+         * cycles per tile].  So the one that is behind gets the higher priority, tile by tile: they stay within a
+         * tile of each other and overlap to the end. */
+#ifndef QPSK_TSCAN_NO_BALANCE      /* A/B builds only */
+        {
+            const int pt = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm->ready[w ^ 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (pt > t) __builtin_amdgcn_s_setprio(2);
+            else if (pt < t) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(1);
+        }
+#endif
         /* window from registers: p0 is even, so a lane's pair is always one aligned 16-byte word of the image */
 #pragma unroll
         for (int ff = 0; ff < UF; ff++) {
@@ -189,11 +222,14 @@ timing_scan_kernel(const float2 *__restrict__ x, int nframes, int frame_size, co
             hist[ff] = pre[ff][1];
         }
         if (t + 1 < ntiles) prefetch(t + 1);
+        tick(0);
         v2f a0, a1, a2, a3, a4, a5, a6, a7;
         fir_full8_asm(rd_addr, tap_addr, a0, a1, a2, a3, a4, a5, a6, a7);
+        tick(1);
         /* the ring slot is free once the scan wave of this frame has finished tile t - DRO */
         if (t >= DRO) ok = wait_ge(&sm->consumed[g >> 2], t - DRO + 1, &sm->abort_flag);
         if (!ok) break;
+        tick(2);
         /* rrc_fir.c:28: y * GAIN in double, narrowed; the lane's 8 outputs are one symbol: two 16-byte words per plane */
         const float2 y0 = fir_gain(make_float2(a0.x, a0.y)), y1 = fir_gain(make_float2(a1.x, a1.y)),
                      y2 = fir_gain(make_float2(a2.x, a2.y)), y3 = fir_gain(make_float2(a3.x, a3.y)),
@@ -206,7 +242,13 @@ timing_scan_kernel(const float2 *__restrict__ x, int nframes, int frame_size, co
         reinterpret_cast<float4 *>(pq)[0] = make_float4(y0.y, y1.y, y2.y, y3.y);
         reinterpret_cast<float4 *>(pq)[1] = make_float4(y4.y, y5.y, y6.y, y7.y);
         if (lane == 0) publish(&sm->ready[w], t + 1);
+        tick(3);
     }
+#ifdef QPSK_PIPE_PROFILE
+    if (prof && lane == 0)
+        printf("timing_scan FIR wave %d: %d tiles; cycles per tile: staging + prefetch %llu, filter %llu, wait for the scan %llu, gain + ring write %llu\n",
+               w, ntiles, tacc[0] / ntiles, tacc[1] / ntiles, tacc[2] / ntiles, tacc[3] / ntiles);
+#endif
     if (!ok && lane == 0) __hip_atomic_store(status, STATUS_PIPE_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -35,12 +35,13 @@ def main():
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=40)
     ap.add_argument("--dbg", default=None)
+    ap.add_argument("--timing", choices=["fixed", "hist", "fft"], default="fixed")
     args = ap.parse_args()
     if args.dbg is not None:
         os.environ["QPSK_PIPE_DBG"] = args.dbg
     dev = torch.device("cuda", 0)
     mods = [load_build(p, str(i)) for i, p in enumerate(args.libs)]
-    modems = [m.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=m.TIMING_FIXED, fixed_index=6) for m in mods]
+    modems = [m.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode={"fixed": m.TIMING_FIXED, "hist": m.TIMING_HIST, "fft": m.TIMING_FFT}[args.timing], fixed_index=6) for m in mods]
     x = bench.synth_frames_gpu(torch, dev, args.frames, modems[0].taps, seed=1)
     sym = torch.empty((args.frames, modems[0].nsym), dtype=torch.uint8, device=dev)
     fr = torch.empty((args.frames,), dtype=torch.float32, device=dev)
