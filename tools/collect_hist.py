@@ -8,7 +8,13 @@ import sys
 
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
+import os
+paths = {}
 for p in glob.glob((sys.argv[1] if len(sys.argv) > 1 else "gpurun_out") + "/hist_*/**/*counter_collection.csv", recursive=True):
+    d = p.split(os.sep)[1]          # one pass per directory: the newest file of each (gpurun merges runs into the same tree)
+    if d not in paths or os.path.getmtime(p) > os.path.getmtime(paths[d]):
+        paths[d] = p
+for p in paths.values():
     for r in csv.DictReader(open(p)):
         k = r["Kernel_Name"].split("(")[0]
         if "qpsk" not in k:
