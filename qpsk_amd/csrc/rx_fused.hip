@@ -1133,12 +1133,19 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
         if (c >= DR) {
             if (!wait_ge(&sm->consumed, c - DR + 1, &sm->abort_flag)) return false;
             tick(0);
-            if (mine) flush_records<GM, R>(a, zring, dring, g, frame, q, c - DR);
+            /* the flush's addresses are recomputed here every time (the asm statement hides that g never changes):
+             * hoisted out of the chunk loop they are spilled, and a scratch reload waits for every load issued before
+             * it -- the next unit's samples, just requested (vmcnt counts in order) */
+            int gf = g, qf = q;
+            asm volatile("" : "+v"(gf), "+v"(qf));
+            if (mine) flush_records<GM, R>(a, zring, dring, gf, f0 + gf, qf, c - DR);
             tick(1);
         }
         if (g < G) {   /* the lane's two symbols are one aligned 16-byte word of the ring (rows are 16-byte aligned, R q even) */
             const float2 s0 = fir_gain(make_float2(ac[0].x, ac[0].y)), s1 = fir_gain(make_float2(ac[1].x, ac[1].y));
-            *reinterpret_cast<float4 *>(dring + (size_t)g * DSTRIDE + (c % DR) * S + R * q) = make_float4(s0.x, s0.y, s1.x, s1.y);
+            int gr = g, qr = q;     /* as above: the ring address is cheaper to recompute than to reload */
+            asm volatile("" : "+v"(gr), "+v"(qr));
+            *reinterpret_cast<float4 *>(dring + (size_t)gr * DSTRIDE + (c % DR) * S + R * qr) = make_float4(s0.x, s0.y, s1.x, s1.y);
         }
         if (lane == 0) st_release(&sm->ready[U.u], c + 1);
         tick(4);

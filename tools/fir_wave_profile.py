@@ -38,9 +38,10 @@ for frames in (4096, 8192):
             print("==== %d frames, %s: skipped (%s)" % (frames, st, e), flush=True)
             continue
         torch.cuda.synchronize()
-        m.tune(pipe_dbg=32)
+        m.tune(pipe_dbg=32 | int(str(st.get("pipe_dbg", 0)), 0))      # a setting's own bits (e.g. the ablations 1, 2) stay on
         print("==== %d frames, %s" % (frames, st), flush=True)
         m.rx_batch_raw(x, frames, sym, fr, ph)
         torch.cuda.synchronize()
         m.tune(pipe_dbg=0)
+        m.tune(pipe_dbg=None)
     del x
