@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Sum rocprofv3 --pmc counter rows per kernel over the gpurun_out/hist_* passes of tools/measure_hist.sh and print
+"""Sum rocprofv3 --pmc counter rows per kernel over the gpurun_out/<prefix>* passes (default hist_: tools/measure_hist.sh;
+sq_4096 / sq_8192: tools/measure_all.sh) and print
 per-launch values (counter values of a kernel are summed over its dispatches' rows and divided by its dispatches)."""
 import csv
 import glob
@@ -10,7 +11,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
 import os
 paths = {}
-for p in glob.glob((sys.argv[1] if len(sys.argv) > 1 else "gpurun_out") + "/hist_*/**/*counter_collection.csv", recursive=True):
+for p in glob.glob((sys.argv[1] if len(sys.argv) > 1 else "gpurun_out") + "/" + (sys.argv[2] if len(sys.argv) > 2 else "hist_") + "*/**/*counter_collection.csv", recursive=True):
     d = p.split(os.sep)[1]          # one pass per directory: the newest file of each (gpurun merges runs into the same tree)
     if d not in paths or os.path.getmtime(p) > os.path.getmtime(paths[d]):
         paths[d] = p

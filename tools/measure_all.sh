@@ -12,11 +12,17 @@ prof prof_8192 python3 bench.py --frames 8192 --cpu-frames 0
 prof prof_fft python3 tools/sweep.py --timing fft
 prof prof_hist2 python3 tools/sweep.py --timing hist
 prof prof_streams3 python3 tools/bench_streams.py
-pmcrun() { d=$1; c=$2; shift 2; timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/$d -- "$@" > $O/$d.log 2>&1; }
+pmcrun() { d=$1; c=$2; shift 2; rm -rf $O/$d; timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/$d -- "$@" > $O/$d.log 2>&1; }
 pmcrun pmc_fetch FETCH_SIZE python3 bench.py --steps 5 --warmup 1 --cpu-frames 0 --no-parity
 pmcrun pmc_write WRITE_SIZE python3 bench.py --steps 5 --warmup 1 --cpu-frames 0 --no-parity
 pmcrun pmc_fetch_8192 FETCH_SIZE python3 bench.py --frames 8192 --steps 5 --warmup 1 --cpu-frames 0 --no-parity
 pmcrun pmc_write_8192 WRITE_SIZE python3 bench.py --frames 8192 --steps 5 --warmup 1 --cpu-frames 0 --no-parity
+# SQ counters of the two receive kernels (profiles/r02_pipe2_sq_counters.txt, r02_pipe1_sq_counters.txt: python tools/collect_hist.py gpurun_out sq_)
+for shape in 4096 8192; do
+  pmcrun sq_${shape}_a "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" python3 bench.py --frames $shape --steps 5 --warmup 1 --cpu-frames 0 --no-parity
+  pmcrun sq_${shape}_b "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU" python3 bench.py --frames $shape --steps 5 --warmup 1 --cpu-frames 0 --no-parity
+  pmcrun sq_${shape}_c "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" python3 bench.py --frames $shape --steps 5 --warmup 1 --cpu-frames 0 --no-parity
+done
 pmcrun pmc_fft_fetch FETCH_SIZE python3 tools/sweep.py --frames 4096 --timing fft --rounds 1 --per-round 2
 pmcrun pmc_fft_write WRITE_SIZE python3 tools/sweep.py --frames 4096 --timing fft --rounds 1 --per-round 2
 timeout -k 10 300 python3 tools/fir_wave_profile.py > $O/fir_wave_profile_final.log 2>&1
