@@ -104,8 +104,10 @@ void qpsk_ctx_destroy(qpsk_ctx *ctx);
 int qpsk_ctx_sync(qpsk_ctx *ctx);
 int qpsk_ctx_set_stream(qpsk_ctx *ctx, void *stream);
 /* Kernel-geometry selection for tests and measurements (never needed for results: every geometry computes the same
- * bits).  Names: "QPSK_PIPE_V", "QPSK_PIPE_G", "QPSK_PIPE_NF", "QPSK_PIPE_WIDE", "QPSK_PIPE_DBG" (layout bits), "QPSK_FUSED_G", "QPSK_FUSED_S",
- * "QPSK_FUSED_LDS", "QPSK_FUSED_GENERIC", "QPSK_HIST_GENERIC"; value < 0 = back to the library's own choice.
+ * bits).  Names: "QPSK_PIPE_V", "QPSK_PIPE_G", "QPSK_PIPE_NF", "QPSK_PIPE_LAYOUT_LO", "QPSK_PIPE_LAYOUT_HI", "QPSK_PIPE_DBG" (layout
+ * bits, csrc/kernels.h), "QPSK_FUSED_G", "QPSK_FUSED_S", "QPSK_FUSED_LDS", "QPSK_FUSED_GENERIC", "QPSK_HIST_GENERIC" (1: histogram
+ * timing through the rrc_fir + scan kernels instead of the fused scan kernel, 2: with the any-CYCLES scan); value < 0 = back
+ * to the library's own choice.
  * Environment variables of the same names are read once, by qpsk_ctx_create(), as the context's initial values;
  * no other call reads the environment, and none of them can change a result. */
 int qpsk_ctx_set_tuning(qpsk_ctx *ctx, const char *name, int value);
