@@ -219,16 +219,18 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
     unsigned long long dummy = 0;
     ctick(dummy);
 #endif
-    /* full chunks behind the first go through the stream that runs across the ring hand-overs (costas_asm.h,
-     * costas_asm_run_ring); the first chunk (loaded state, 4-symbol alignment of the stream), a last partial one and
-     * the variants below stay chunk by chunk */
+    /* full chunks go through the stream that runs across the ring hand-overs (costas_asm.h, costas_asm_run_ring); a
+     * first chunk that starts from a loaded phase of -0, a last partial one and the variants below stay chunk by chunk */
 #ifdef QPSK_PIPE_PROFILE
     const bool ring_stream = fast_clamp && !(a.dbg & (2 | 8 | 16 | 32)) && S == 4 * COSTAS_ASM_GROUP && DR == 2;
 #else
     const bool ring_stream = fast_clamp && !(a.dbg & (8 | 16)) && S == 4 * COSTAS_ASM_GROUP && DR == 2;
 #endif
+    /* the frame's first chunk goes through the stream too unless some loop starts from a LOADED phase of -0 (the
+     * stream's sin/cos form is exact everywhere else; a -0 frequency is kept away from it group by group below) */
+    const int first_ring_chunk = __any(active && __float_as_uint(ph) == 0x80000000u) ? 1 : 0;
     for (int c = 0; c < nchunks && ok; c++) {
-        if (ring_stream && c >= 1 && (c + 1) * S <= N) {
+        if (ring_stream && c >= first_ring_chunk && (c + 1) * S <= N) {
             const int cfull = N / S;      /* chunks c .. cfull - 1 are whole */
             if (active) {
                 constexpr int AG = COSTAS_ASM_GROUP;
