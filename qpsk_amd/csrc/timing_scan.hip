@@ -31,10 +31,6 @@
 #include "qpsk_device.h"
 #include "costas_asm.h"      /* lds_addr() */
 #include "fir_full8_asm.h"
-#ifdef QPSK_TSCAN_NOLDS      /* timing experiment only (tools): the filter stream without its LDS reads */
-#include "../../build_ubench/fir_full8_nolds_asm.h"
-#define fir_full8_asm fir_full8_nolds_asm
-#endif
 #include "kernels.h"
 
 namespace qpsk {
