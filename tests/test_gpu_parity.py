@@ -373,6 +373,16 @@ def test_empty_and_bad_calls_are_rejected():
     assert L.qpsk_fft_batch(m.h, C.c_void_p(x.data_ptr()), C.c_void_p(x.data_ptr()), 1, 24, 0) == -2      # not a power of two
     assert L.qpsk_streams_rx_cplx(m.h, C.c_void_p(x.data_ptr()), None, None, None, None, None) == -5    # no qpsk_streams_reset yet
     import qpsk_amd
+    # the fused scan kernel's conditions are checked, not assumed: whole 256-sample tiles, CYCLES = 8, aligned input
+    m2 = modem(fs=19200.0, rs=2400.0, frame_size=1000)
+    with pytest.raises(qpsk_amd.QpskError, match="frame_size"):
+        m2.timing_scan(np.zeros((2, 1000, 2), np.float32))
+    m3 = modem(fs=9600.0, rs=2400.0, frame_size=1024)
+    with pytest.raises(qpsk_amd.QpskError, match="CYCLES"):
+        m3.timing_scan(np.zeros((2, 1024, 2), np.float32))
+    xo = torch.zeros((2 * 1024 * 2 + 2,), dtype=torch.float32, device="cuda")[2:]                        # 8 bytes off a 16-byte boundary
+    idx = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    assert L.qpsk_timing_scan_batch(m.h, C.c_void_p(xo.data_ptr()), 2, C.c_void_p(idx.data_ptr()), None) == -2
     with pytest.raises(qpsk_amd.QpskError):
         qpsk_amd.Modem(fs=9600.0, rs=2400.0, frame_size=510)                                              # 510 % 4 != 0
     with pytest.raises(qpsk_amd.QpskError):
