@@ -27,7 +27,7 @@ struct FusedArgs {
     const int32_t *index;   /* [nframes] or NULL -> fixed_index */
     int fixed_index;
     int dbg;                /* layout variants of the pipeline kernel, all bit-exact (qpsk_ctx_set_tuning "QPSK_PIPE_DBG"):
-                               4 no spare waves, 8 C++ Costas step, 16 serial wave chunk by chunk (no stream across the ring hand-overs), 128 one lane mapping for all FIR waves (the plain
+                               4 no spare waves, 8 C++ Costas step, 16 serial wave chunk by chunk (no stream across the ring hand-overs), 64 FIR waves that share a SIMD keep their hardware order (16-frame kernel), 128 one lane mapping for all FIR waves (the plain
                                layout).  Measurement build only (-DQPSK_PIPE_PROFILE; masked off by api.cpp otherwise):
                                1 skip FIR arithmetic, 2 skip the Costas recurrence (both change the result), 32 print the
                                cycle accounting of workgroup 0's FIR waves */

@@ -859,8 +859,19 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     prefetch(own, pre, 0);
     bool ok = true;
     tick(-1);
-    for (int c = 0; c < nchunks && ok; c++)
+    for (int c = 0; c < nchunks && ok; c++) {
+        /* mixed layout: SIMDs 2 and 3 each carry a four-frame wave and a (younger) two-frame wave, and a SIMD serves
+         * its oldest wave first -- the two-frame waves were the ones with no slack.  The wave that is behind its SIMD
+         * partner goes first, chunk by chunk (as in timing_scan_kernel): 1-2 % at config 2 (0.1707 against 0.1741 ms and
+         * 0.1745 against 0.1757 ms in two same-process runs; QPSK_PIPE_DBG bit 64 = without). */
+        if (a.mixed == 1 && w >= 1 && !(a.dbg & 64)) {
+            const int pt = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm->ready[w <= 2 ? w + 2 : w - 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (pt > c) __builtin_amdgcn_s_setprio(2);
+            else if (pt < c) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(1);
+        }
         ok = run_chunk(own, pre, c, c + 1 < nchunks);
+    }
     if (ok) {
         ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
         if (ok)
