@@ -3,13 +3,13 @@
  * instruction stream, for the serial wave of rx_fused_pipe_kernel.
  *
  * Why assembly: the recurrence runs in ONE wave per workgroup and that wave is strictly in order.  Measured
- * on MI355X with timing-only variants of this stream inside the kernel (tools/ab_libs.py): the
- * step is ISSUE bound.  The lone wave issues a VALU instruction every 4 cycles and loses 4 more wherever an
- * instruction needs the result of the one right before it (5.2 cycles per instruction on average: one more or
- * less is ~5.5, while taking dependent operations off the critical path without removing such adjacencies changes
- * nothing); an LDS instruction costs it 15-25 cycles almost regardless of its size (16 -> 12 -> 4 bytes per step:
- * -2.4 %, then -1 %; one write per 16 steps instead of one per step: -8 %); a not-taken branch on a VALU compare
- * ~10.  The compiler's version of the step ran ~355 cycles.  What this stream does about it:
+ * on MI355X (timing-only variants of this stream inside the kernel in round 1, tools/ab_libs.py; the stream alone
+ * on a CU with pieces removed in round 2, tools/ubench_step.py, profiles/r02_step_cost.txt): the step is ISSUE
+ * bound.  The wave pays ~4.5-5.8 cycles per VALU instruction whether or not it depends on the one before (the "8
+ * cycles per dependent instruction" of round 1's notes came from one-instruction asm statements, which the compiler
+ * pads with s_nop), ~16-21 per LDS instruction almost regardless of its size (16 -> 12 -> 4 bytes per step: -2.4 %,
+ * then -1 %; one write per 16 steps instead of one per step: -8 %), 13-15 for the per-step wrap test's branch with
+ * the wraps it takes.  The compiler's version of the step ran ~355 cycles.  What this stream does about it:
  *   - 28 VALU instructions per step;
  *   - the only thing a step leaves behind is the PHASE it started from (the FIR waves' flush redoes sin/cos and
  *     the rotation from it, bit for bit the same operations): four steps' phases sit in v140..v143 and go to LDS
