@@ -101,28 +101,63 @@ def cpu_baseline(x_host, taps):
 
 def launch_ranks(n, argv):
     """Start n ranks of this script as child processes (plain subprocess, never an exec of a process that has
-    initialised the GPU), relay rank 0's single JSON line; returns the exit status (non-zero if any rank failed)."""
+    initialised the GPU), relay rank 0's single JSON line; returns the exit status (non-zero if any rank failed).
+    All children are polled: the first one to fail ends the others at once (they would otherwise sit in the
+    rendezvous until its timeout), and a bind that lost the race for its port is retried once."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print("bench.py: ranks failed: %s" % bad, file=sys.stderr)
-        return 1
-    return 0
+    import tempfile
+    for attempt in range(2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs, outs = [], []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            out = tempfile.TemporaryFile() if r == 0 else subprocess.DEVNULL
+            err = tempfile.TemporaryFile()
+            outs.append((out, err))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out, stderr=err))
+        rcs = [None] * n
+        while any(rc is None for rc in rcs):
+            for r, p_ in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = p_.poll()
+            if any(rc not in (None, 0) for rc in rcs):
+                # a rank failed: the others get a moment to fail by themselves (the same cause, usually), then go
+                t_grace = time.time() + 3.0
+                for r, p_ in enumerate(procs):       # our own children, by handle
+                    if rcs[r] is None:
+                        try:
+                            rcs[r] = p_.wait(timeout=max(0.0, t_grace - time.time()))
+                        except subprocess.TimeoutExpired:
+                            p_.kill()
+                            p_.wait()
+                            rcs[r] = -9
+                break
+            time.sleep(0.05)
+        errs = []
+        for r, (out, err) in enumerate(outs):
+            err.seek(0)
+            errs.append(err.read().decode(errors="replace"))
+            err.close()
+        sys.stderr.write("".join(errs))
+        outs[0][0].seek(0)
+        line = outs[0][0].read().decode()
+        outs[0][0].close()
+        if attempt == 0 and any(rc != 0 for rc in rcs) and any("EADDRINUSE" in e or "Address already in use" in e for e in errs):
+            continue
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (0, -9)] or [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+        if bad:
+            print("bench.py: ranks failed: %s" % bad, file=sys.stderr)
+            return 1
+        return 0
+    return 1
 
 
 def note(msg):
@@ -142,6 +177,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=2048,
                     help="frames of the CPU baseline sample (0 = skip); 2048 = half a batch, ~12 s of the reference on one core")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-shard", action="store_true",
+                    help="N = 1, config 2 only: skip the extra measurement of the 8192-frame per-GPU share (key shard_8192)")
     ap.add_argument("--settle", type=float, default=0.25, help="seconds of untimed launches before the warmup steps (GPU clocks)")
     ap.add_argument("--frame-size", type=int, default=L, help="complex samples per frame (config 2: 16384)")
     args = ap.parse_args()
@@ -167,70 +204,88 @@ def main():
     import torch
     import qpsk_amd
 
-    from qpsk_amd.shard import (env_rank_world, init_distributed, local_device, max_over_ranks, shard_range,
-                                sum_over_ranks)
+    from qpsk_amd.shard import (device_identity, distinct_devices, env_rank_world, gather_identities, init_distributed,
+                                local_device, max_over_ranks, shard_range, sum_over_ranks)
     rank, local, world = env_rank_world()
+    # The control plane (barrier, two scalar reductions, the ranks' device identities) is host data over gloo whatever
+    # the number of GPUs: the data path has no collective (north_star), so no rank creates an RCCL communicator and
+    # the N = 8 run executes the control code that the two-rank rehearsal on a one-GPU box and the CPU tests execute.
+    dist = init_distributed("gloo")               # None when WORLD_SIZE == 1; before anything touches the GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libqpsk_hip has no CPU path")
     ndev = torch.cuda.device_count()
     local = local_device(local, ndev)             # one GPU per rank; ranks share only when the box has fewer GPUs
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # nccl == RCCL on ROCm (one GPU per rank); ranks that share a GPU (rehearsal on a smaller box) meet over gloo
-    shared = world > ndev
-    dist = init_distributed("gloo" if shared else "nccl", None if shared else dev)   # None when WORLD_SIZE == 1
-    rdev = None if shared else dev
+    idents = gather_identities(device_identity(torch, local), dist)
     if not os.path.exists(qpsk_amd.lib_path()):
         if rank == 0:
             qpsk_amd.build()
         if dist:
             dist.barrier()
 
-    # the job is world * args.frames independent frames; this rank demodulates its contiguous shard of them
-    lo, hi = shard_range(world * args.frames, rank, world)
-    F = hi - lo
-    m = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX,
-                       device=local)
-    note("context ready, generating %d frames" % F)
-    x = synth_frames_gpu(torch, dev, F, m.taps, seed=1000 + rank)
-    torch.cuda.synchronize()
-    note("frames ready")
-    sym = torch.empty((F, m.nsym), dtype=torch.uint8, device=dev)
-    freq = torch.empty((F,), dtype=torch.float32, device=dev)
-    phase = torch.empty((F,), dtype=torch.float32, device=dev)
-
     def barrier():
         if dist:
             dist.barrier()
 
-    # clock settle, before the W warmup steps and outside every count: a step is 0.2-0.3 ms, so W + K = 25 steps are
-    # over in 5 ms, before the GPU has left its idle clocks (the same 20 steps read 6-8 % longer cold than after
-    # 0.1 s of work).  The timed region below is still exactly K steps after exactly W warmup steps.
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle:
-        for _ in range(10):
-            m.rx_batch_raw(x, F, sym, freq, phase)
+    def make_batch(F, seed):
+        m_ = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX,
+                            device=local)
+        x_ = synth_frames_gpu(torch, dev, F, m_.taps, seed=seed)
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        m.rx_batch_raw(x, F, sym, freq, phase)
-    torch.cuda.synchronize()
-    note("warmup done")
-    barrier()
-    torch.cuda.synchronize()
-    # a step is ONE launch of the dominant kernel, so its average duration is the span of the timed region on the
-    # launch stream (= torch's current stream) over K: HIP events around the K back-to-back launches
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        m.rx_batch_raw(x, F, sym, freq, phase)
-    ev1.record()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, dist, rdev)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    m.sync()      # raises if a kernel's in-LDS pipeline gave up (bounded spins): such a run has no valid timing
-    joined = int(round(sum_over_ranks(1, dist, rdev)))      # ranks that really took part
+        return m_, x_, (torch.empty((F, m_.nsym), dtype=torch.uint8, device=dev),
+                        torch.empty((F,), dtype=torch.float32, device=dev),
+                        torch.empty((F,), dtype=torch.float32, device=dev))
+
+    def timed_region(m_, x_, F, outs, steps, warmup, settle):
+        """W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides.  Returns (wall
+        seconds of the K steps on this rank, kernel ms per launch from HIP events on the launch stream)."""
+        sym_, freq_, phase_ = outs
+        # clock settle, before the W warmup steps and outside every count: a step is 0.2-0.3 ms, so W + K = 25 steps
+        # are over in 5 ms, before the GPU has left its idle clocks (DESIGN.md 6)
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < settle:
+            for _ in range(10):
+                m_.rx_batch_raw(x_, F, sym_, freq_, phase_)
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            m_.rx_batch_raw(x_, F, sym_, freq_, phase_)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        # a step is ONE launch of the dominant kernel, so its average duration is the span of the timed region on the
+        # launch stream (= torch's current stream, which the context enqueues on) over K
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(steps):
+            m_.rx_batch_raw(x_, F, sym_, freq_, phase_)
+        ev1.record()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        m_.sync()      # raises if a kernel's in-LDS pipeline gave up (bounded spins): such a run has no valid timing
+        return dt, ev0.elapsed_time(ev1) / steps
+
+    def hz_check(freq_):
+        """every frame of the batch must have locked on the +50 Hz carrier of the stimulus (qpsk.c:217)"""
+        hz = freq_.double() * RS / (2 * np.pi)
+        return int(freq_.numel()), int(((hz - 50.0).abs() >= 2.0).sum().item()), float(hz.mean().item())
+
+    # the job is world * args.frames independent frames; this rank demodulates its contiguous shard of them
+    lo, hi = shard_range(world * args.frames, rank, world)
+    F = hi - lo
+    note("generating %d frames" % F)
+    m, x, outs = make_batch(F, seed=1000 + rank)
+    sym, freq, phase = outs
+    note("frames ready")
+    dt, kernel_ms = timed_region(m, x, F, outs, args.steps, args.warmup, args.settle)
+    elapsed = max_over_ranks(dt, dist)
+    joined = int(round(sum_over_ranks(1, dist)))      # ranks that really took part
+    kernel_name = m.last_kernel()                     # reported by the library, not inferred from the shape
+    hz_n, hz_bad, hz_mean = hz_check(freq)
+    hz_bad_all = int(round(sum_over_ranks(hz_bad, dist)))
+    hz_n_all = int(round(sum_over_ranks(hz_n, dist)))
 
     # cross-check, outside the timed region: one event pair per launch (each pair adds its own ~2 us)
     nev = min(args.steps, 50)
@@ -248,50 +303,93 @@ def main():
             dist.destroy_process_group()
         return
 
-    samples_per_step = world * F * L
-    value = samples_per_step * args.steps / elapsed / 1e6
-    achieved = BYTES_PER_SAMPLE * F * L / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):   # PMC bytes per launch of this shape's kernel (tools/collect_profiles.py), if it was profiled
+    def traffic_of(F_):
+        """PMC bytes per launch of this shape's kernel from an EARLIER rocprofv3 --pmc session of this command
+        (profiles/traffic.json, tools/collect_profiles.py) -- a constant of the code version profiled, not a counter
+        of this run; the source says which file and when."""
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
         try:
             tj = json.load(open(tpath))
-            tj = tj.get("shapes", {}).get("%dx%d" % (F, L), tj)
-            if tj.get("frames") == F and tj.get("frame_size") == L:
-                traffic = tj.get("hbm_bytes_per_launch")
+            tj = tj.get("shapes", {}).get("%dx%d" % (F_, L), tj)
+            if tj.get("frames") == F_ and tj.get("frame_size") == L:
+                return tj.get("hbm_bytes_per_launch"), {
+                    "file": "profiles/traffic.json", "from": tj.get("source"),
+                    "file_mtime": time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(tpath))),
+                    "kernel_profiled": tj.get("kernel"),
+                    "note": "PMC FETCH_SIZE x 2 + WRITE_SIZE of an earlier profiling session, not a counter of this run"}
         except Exception:
-            traffic = None
-    kernel_name = "rx_pipe2_kernel" if F > 16 * torch.cuda.get_device_properties(dev).multi_processor_count else "rx_fused_pipe_kernel"
+            pass
+        return None, None
+
+    def roofline_of(F_, kms, kname):
+        ach = BYTES_PER_SAMPLE * F_ * L / (kms * 1e-3) / 1e9
+        tr, src = traffic_of(F_)
+        return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "kernel_ms": kms,
+                "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * F_ * L}
+
+    import hashlib
+    lib_file = qpsk_amd.lib_path()
+    ndistinct = distinct_devices(idents)
+    samples_per_step = world * F * L
+    value = samples_per_step * args.steps / elapsed / 1e6
+    rl = roofline_of(F, kernel_ms, kernel_name)
+    rl["kernel_ms_event_pair_per_launch"] = kernel_ms_pairs
     res = {
         "metric": "complex Msamples/s demodulated + % HBM roofline, 2400-baud RRC+Costas path",
-        "value": value, "unit": "Msamples/s", "n_gpus": joined, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "Msamples/s", "n_gpus": ndistinct, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "clock_settle_s": args.settle,
+        # n_gpus counts DISTINCT physical devices (host + PCI address of every rank, gathered); ranks that share a GPU
+        # (a rehearsal of the launch path on a smaller box) show up as ranks > n_gpus and gpu_shared
+        "ranks": joined, "gpu_shared": ndistinct < joined, "devices": idents,
+        "control_plane": "gloo (host scalars only: barrier, max of elapsed, device identities); data path: no collective",
         "config": {"workload": "batch %d frames x %d complex samples per GPU, 2400 baud, 8x oversample, fused RRC FIR + Costas + slicer, fixed timing offset %d (%s)" % (
                        F, L, FIXED_INDEX, "BASELINE configs[1]" if (F, L) == (4096, 16384) else
                        "BASELINE configs[3] per-GPU share" if (F, L) == (8192, 16384) else "non-BASELINE shape"),
                    "frames_per_gpu": F, "frames_total": world * F, "gpus_visible_per_rank_box": ndev, "frame_size": L, "fs": FS, "rs": RS, "loop_bw": "TAU/100", "sharding": "independent frames per GPU, no collective"},
-        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kernel_ms,
-                     "kernel_ms_event_pair_per_launch": kernel_ms_pairs,
-                     "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * F * L},
+        "roofline": rl,
+        "library": {"path": os.path.relpath(lib_file, ROOT) if lib_file.startswith(ROOT) else lib_file,
+                    "sha256": hashlib.sha256(open(lib_file, "rb").read()).hexdigest(),
+                    "override_QPSK_HIP_LIB": bool(os.environ.get("QPSK_HIP_LIB")), "version": qpsk_amd.version()},
     }
+    parity = {"hz_frames_checked": hz_n_all, "hz_out_of_range": hz_bad_all, "mean_freq_hz": hz_mean}
+    if not args.no_parity:       # parity gate of the same run (rank 0's shard): bits against the oracle
+        from oracle.pyoracle import Oracle, TIMING_FIXED
+        npar = min(256, F)
+        xh = x[:npar].cpu().numpy()
+        want = Oracle().rx_batch(xh, FS, RS, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX)
+        gs, gf, gp = sym[:npar].cpu().numpy(), freq[:npar].cpu().numpy(), phase[:npar].cpu().numpy()
+        parity.update({"frames_checked": npar, "symbol_mismatches": int(np.sum(gs != want["sym"])),
+                       "freq_bit_mismatches": int(np.sum(gf.view(np.uint32) != want["freq"].view(np.uint32))),
+                       "phase_bit_mismatches": int(np.sum(gp.view(np.uint32) != want["phase"].view(np.uint32)))})
+    res["parity"] = parity
     if world == 1:          # the CPU baseline is reported at N = 1 only
         ncpu = min(args.cpu_frames, F)
         if ncpu > 0:
             xh = x[:ncpu].cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(xh, m.taps)
-    if True:                # parity gate of the same run (rank 0's shard)
+    if world == 1 and (F, L) == (FRAMES_1GPU, 16384) and not args.no_shard:
+        # BASELINE configs[3]'s per-GPU share (8192 x 16384: the shape of every rank of an N > 1 run, and the one where
+        # the filter, not the recurrence, is the limit) measured in the same run, after config 2's region and by the
+        # same timed-region code.  `value`, `config` and `roofline` above stay config 2's.
+        del x, outs, sym, freq, phase
+        m.close()
+        torch.cuda.empty_cache()
+        F2 = FRAMES_PER_GPU_SHARDED
+        m2, x2, outs2 = make_batch(F2, seed=2000)
+        dt2, kms2 = timed_region(m2, x2, F2, outs2, args.steps, args.warmup, args.settle)
+        n2, bad2, mean2 = hz_check(outs2[1])
+        sh = roofline_of(F2, kms2, m2.last_kernel())
+        sh.update({"frames": F2, "frame_size": L, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": dt2 / args.steps * 1e3, "msamples_per_s": F2 * L * args.steps / dt2 / 1e6,
+                   "hz_frames_checked": n2, "hz_out_of_range": bad2, "mean_freq_hz": mean2})
         if not args.no_parity:
             from oracle.pyoracle import Oracle, TIMING_FIXED
-            npar = min(256, F)
-            xh = x[:npar].cpu().numpy()
+            xh = x2[:64].cpu().numpy()
             want = Oracle().rx_batch(xh, FS, RS, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX)
-            gs, gf, gp = sym[:npar].cpu().numpy(), freq[:npar].cpu().numpy(), phase[:npar].cpu().numpy()
-            res["parity"] = {"frames_checked": npar, "symbol_mismatches": int(np.sum(gs != want["sym"])),
-                             "freq_bit_mismatches": int(np.sum(gf.view(np.uint32) != want["freq"].view(np.uint32))),
-                             "phase_bit_mismatches": int(np.sum(gp.view(np.uint32) != want["phase"].view(np.uint32))),
-                             "mean_freq_hz": float(np.mean(gf.astype(np.float64) * RS / (2 * np.pi)))}
+            sh["symbol_mismatches_64_frames"] = int(np.sum(outs2[0][:64].cpu().numpy() != want["sym"]))
+        res["shard_8192"] = sh
     print(json.dumps(res), file=real_stdout, flush=True)
     if dist:
         dist.barrier()

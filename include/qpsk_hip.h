@@ -113,6 +113,10 @@ int qpsk_ctx_set_stream(qpsk_ctx *ctx, void *stream);
 int qpsk_ctx_set_tuning(qpsk_ctx *ctx, const char *name, int value);
 int qpsk_ctx_cycles(const qpsk_ctx *ctx);   /* CYCLES */
 int qpsk_ctx_nsym(const qpsk_ctx *ctx);     /* FRAME_SIZE / CYCLES */
+/* Name of the receive kernel the context's last qpsk_rx_batch() / qpsk_rx_batch_bw() launched ("" before the first
+ * call): which of the library's geometries served that batch shape.  For measurement records (bench.py), not
+ * results -- every geometry computes the same bits.  The string is static storage. */
+const char *qpsk_ctx_last_kernel(const qpsk_ctx *ctx);
 
 /* Host-side copies of what rrc_make() / create_control_loop() produced for this context. */
 int qpsk_ctx_get_taps(const qpsk_ctx *ctx, float h_taps[QPSK_NTAPS]);

@@ -8,4 +8,4 @@ device pointers of torch tensors (PyTorch is used for device memory and streams,
 There is no CPU fallback: without the built library, or without a GPU, everything raises.
 """
 from .lib import (QpskError, Modem, Params, TIMING_FIXED, TIMING_FFT, TIMING_HIST, build, lib_path, load,  # noqa: F401
-                  TAU)
+                  TAU, version)

@@ -89,6 +89,7 @@ struct qpsk_ctx {
     int device = 0;
     Tuning tune;
     int ncu = 256;                /* compute units of the device (256 on MI355X) */
+    const char *last_kernel = ""; /* the receive kernel the last rx batch launched (qpsk_ctx_last_kernel) */
     hipStream_t stream = nullptr; /* caller's stream; nullptr = default stream */
     qpsk_params prm{};
     int cycles = 0, nsym = 0;
@@ -175,7 +176,7 @@ static int use_context_gains(qpsk_ctx *c)
 extern "C" {
 
 const char *qpsk_last_error(void) { return g_err; }
-const char *qpsk_version(void) { return "qpsk_hip 0.1 (gfx950)"; }
+const char *qpsk_version(void) { return "qpsk_hip 0.3 (gfx950)"; }
 
 int qpsk_device_count(void)
 {
@@ -339,6 +340,7 @@ int qpsk_ctx_set_tuning(qpsk_ctx *c, const char *name, int value)
 
 int qpsk_ctx_cycles(const qpsk_ctx *c) { return c ? c->cycles : 0; }
 int qpsk_ctx_nsym(const qpsk_ctx *c) { return c ? c->nsym : 0; }
+const char *qpsk_ctx_last_kernel(const qpsk_ctx *c) { return c ? c->last_kernel : ""; }
 
 int qpsk_ctx_get_taps(const qpsk_ctx *c, float *h)
 {
@@ -549,6 +551,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
             }
         }
         KERNEL_TRY(launch_rx_pipe2(a, G, layout, c->d_status, c->stream));
+        c->last_kernel = "rx_pipe2_kernel";
     } else if (pipe_ok) {
         /* 16-frame workgroups (four FIR waves of four frames, fewer when the batch gives a CU fewer frames); a batch
          * above 16 frames per CU would run them in rounds */
@@ -565,8 +568,10 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
         if (!fits(nf))
             return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame", nf, nbw);
         KERNEL_TRY(launch_rx_fused_pipe(a, nf, c->d_status, c->stream));
+        c->last_kernel = "rx_fused_pipe_kernel";
     } else {
         KERNEL_TRY(launch_rx_fused(a, c->stream));
+        c->last_kernel = "rx_fused_kernel";
     }
     if (d_index) {
         if (idx)

@@ -45,6 +45,7 @@ _LIB = None
 API_SYMBOLS = [
     "qpsk_last_error", "qpsk_version", "qpsk_device_count", "qpsk_params_default", "qpsk_ctx_create",
     "qpsk_ctx_destroy", "qpsk_ctx_sync", "qpsk_ctx_set_stream", "qpsk_ctx_set_tuning", "qpsk_ctx_cycles", "qpsk_ctx_nsym",
+    "qpsk_ctx_last_kernel",
     "qpsk_ctx_get_taps", "qpsk_ctx_get_gains", "qpsk_ctx_set_taps", "qpsk_ctx_set_loop", "qpsk_rx_batch",
     "qpsk_rx_batch_bw", "qpsk_rrc_fir_batch", "qpsk_timing_hist_batch", "qpsk_timing_scan_batch", "qpsk_timing_fft_batch", "qpsk_costas_batch", "qpsk_fft_batch",
     "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
@@ -93,6 +94,8 @@ def load():
     L.qpsk_ctx_set_tuning.argtypes = [vp, C.c_char_p, i32]
     L.qpsk_ctx_cycles.argtypes = [vp]
     L.qpsk_ctx_nsym.argtypes = [vp]
+    L.qpsk_ctx_last_kernel.argtypes = [vp]
+    L.qpsk_ctx_last_kernel.restype = C.c_char_p
     L.qpsk_ctx_get_taps.argtypes = [vp, C.POINTER(f32)]
     L.qpsk_ctx_get_gains.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
     L.qpsk_ctx_set_taps.argtypes = [vp, C.POINTER(f32)]
@@ -119,6 +122,11 @@ def load():
     L.qpsk_tx_symbols.argtypes = [vp, vp, i32, vp, vp]
     _LIB = L
     return L
+
+
+def version():
+    """qpsk_version() of the loaded library"""
+    return load().qpsk_version().decode()
 
 
 def _ptr(t):
@@ -169,6 +177,10 @@ class Modem:
 
     def sync(self):
         self._check(self.L.qpsk_ctx_sync(self.h))
+
+    def last_kernel(self):
+        """Name of the receive kernel the last rx_batch*() call launched (which geometry served that shape)."""
+        return self.L.qpsk_ctx_last_kernel(self.h).decode()
 
     def tune(self, **kw):
         """Kernel-geometry selection (tests, measurements): m.tune(pipe_nf=3, pipe_wide=0); None = library's choice.

@@ -31,9 +31,12 @@ def test_bench_defaults_are_the_contract_defaults():
 def test_bench_json_line():
     d = run_bench("--steps", "5", "--warmup", "2", "--frames", "256", "--cpu-frames", "8")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "ranks", "gpu_shared",
+              "devices", "library", "control_plane"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
+    assert d["ranks"] == 1 and d["gpu_shared"] is False and len(d["devices"]) == 1 and d["devices"][0]["rank"] == 0
+    assert "shard_8192" not in d        # only beside config 2 itself (4096 x 16384), see test_bench_shard_key below
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["unit"] == "Msamples/s" and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -49,12 +52,50 @@ def test_bench_json_line():
     # achieved = algorithmic bytes per launch over the kernel's average duration
     assert abs(rl["achieved"] - rl["algorithmic_bytes_per_launch"] / (rl["kernel_ms"] * 1e-3) / 1e9) / rl["achieved"] < 1e-9
     assert rl["algorithmic_bytes_per_launch"] == 8 * 256 * d["config"]["frame_size"]
+    # provenance: the kernel name comes from the library, the traffic constant names its source (none for this shape),
+    # the library file that was actually loaded is identified by path and hash
+    assert rl["kernel"] in ("rx_fused_pipe_kernel", "rx_pipe2_kernel", "rx_fused_kernel") and "traffic_source" in rl
+    assert rl["traffic"] is None and rl["traffic_source"] is None
+    import hashlib
+    lib = d["library"]
+    assert lib["override_QPSK_HIP_LIB"] is False and lib["path"] == os.path.join("qpsk_amd", "libqpsk_hip.so")
+    assert lib["sha256"] == hashlib.sha256(open(os.path.join(ROOT, lib["path"]), "rb").read()).hexdigest()
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     p = d["parity"]
     assert p["symbol_mismatches"] == 0 and p["freq_bit_mismatches"] == 0 and p["phase_bit_mismatches"] == 0
+    assert p["hz_frames_checked"] == 256 and p["hz_out_of_range"] == 0       # EVERY frame locked on the +50 Hz carrier
+
+
+def test_bench_shard_key_is_wired_to_config_2():
+    """the 8192-frame per-GPU share rides along in the N = 1 line as `shard_8192` (its own timed region, the same
+    code), without touching `value` / `config` / `roofline`"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'res["shard_8192"] = sh' in src and "(F, L) == (FRAMES_1GPU, 16384) and not args.no_shard" in src
+    assert src.count("timed_region(") == 3          # the definition and its two uses
+
+
+def test_control_plane_is_gloo_only():
+    """no rank ever creates an RCCL communicator: the N = 8 run executes the control code of the rehearsals"""
+    src = open(os.path.join(ROOT, "bench.py")).read() + open(os.path.join(ROOT, "qpsk_amd", "shard.py")).read()
+    assert 'init_process_group("gloo"' in src and '"nccl"' not in src.replace('backend "nccl"', "")
+    from qpsk_amd.shard import distinct_devices, init_distributed
+    with pytest.raises(ValueError):
+        os.environ["WORLD_SIZE"] = "2"
+        try:
+            init_distributed("nccl")
+        finally:
+            del os.environ["WORLD_SIZE"]
+    a = {"rank": 0, "host": "h", "pci_bus_id": "0000:05:00", "uuid": None, "visible": None, "device": 0}
+    b = dict(a, rank=1)
+    c = dict(a, rank=2, pci_bus_id="0000:06:00", device=1)
+    assert distinct_devices([a]) == 1 and distinct_devices([a, b]) == 1 and distinct_devices([a, b, c]) == 2
+    # per-rank visibility masks: every rank sees "device 0" of a different GPU
+    m0 = {"rank": 0, "host": "h", "pci_bus_id": None, "uuid": None, "visible": "3", "device": 0}
+    m1 = dict(m0, rank=1, visible="4")
+    assert distinct_devices([m0, m1]) == 2
 
 
 @pytest.mark.gpu

@@ -92,8 +92,10 @@ def test_two_ranks_through_the_hip_library(tmp_path):
 
 @pytest.mark.gpu
 def test_bench_gpus_2_starts_two_ranks():
-    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) must start two ranks itself and say n_gpus = 2;
-    on a 1-GPU box both ranks share the GPU (a rehearsal of the launch path, not a scaling number)."""
+    """`python bench.py --gpus 2` (no WORLD_SIZE in the environment) must start two ranks itself; its line says how
+    many ranks ran (`ranks`) and how many DISTINCT GPUs they used (`n_gpus`, from the gathered device identities): on
+    a 1-GPU box both ranks share the GPU (`gpu_shared`: a rehearsal of the launch path, not a scaling number).  The
+    control plane is the one an 8-GPU run executes (gloo, host scalars)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--frames", "64", "--frame-size", "2048"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -101,8 +103,17 @@ def test_bench_gpus_2_starts_two_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 64 and d["config"]["frames_total"] == 128
-    assert d["parity"]["symbol_mismatches"] == 0 and "cpu_baseline" not in d
+    assert d["ranks"] == 2 and d["config"]["frames_per_gpu"] == 64 and d["config"]["frames_total"] == 128
+    assert d["parity"]["symbol_mismatches"] == 0 and "cpu_baseline" not in d and "shard_8192" not in d
+    assert d["parity"]["hz_frames_checked"] == 128 and d["parity"]["hz_out_of_range"] == 0     # both ranks' frames
+    # n_gpus is backed by the ranks' gathered device identities: distinct (host, PCI address) pairs
+    import torch
+    devs = d["devices"]
+    assert [x["rank"] for x in devs] == [0, 1] and all(x["host"] and x["name"] for x in devs)
+    keys = {(x["host"], x["pci_bus_id"] or x["uuid"] or (x["visible"], x["device"])) for x in devs}
+    assert d["n_gpus"] == len(keys) == min(2, torch.cuda.device_count())
+    assert d["gpu_shared"] == (torch.cuda.device_count() < 2)
+    assert d["control_plane"].startswith("gloo")
 
 
 def test_bench_gpus_flag_is_not_ignored():
