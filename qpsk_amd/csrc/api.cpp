@@ -90,6 +90,7 @@ struct qpsk_ctx {
     Tuning tune;
     int ncu = 256;                /* compute units of the device (256 on MI355X) */
     const char *last_kernel = ""; /* the receive kernel the last rx batch launched (qpsk_ctx_last_kernel) */
+    bool taps_symmetric = false;  /* taps[k] == taps[126 - k] bit for bit: rx_lean_kernel keeps the 64 distinct ones in SGPRs */
     hipStream_t stream = nullptr; /* caller's stream; nullptr = default stream */
     qpsk_params prm{};
     int cycles = 0, nsym = 0;
@@ -204,6 +205,9 @@ static int upload_config(qpsk_ctx *c)
     float t128[128];
     memset(t128, 0, sizeof t128);
     memcpy(t128, c->taps, sizeof c->taps);
+    c->taps_symmetric = true;
+    for (int k = 0; k < QPSK_NTAPS / 2; k++)
+        if (memcmp(&c->taps[k], &c->taps[QPSK_NTAPS - 1 - k], sizeof(float)) != 0) c->taps_symmetric = false;
     HIP_TRY(hipMemcpyAsync(c->d_taps, t128, sizeof t128, hipMemcpyHostToDevice, c->stream));
     const float g[2] = {c->alpha, c->beta};
     c->h_gains.assign(g, g + 2);
@@ -522,56 +526,108 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
      * 16-frame workgroups of rx_fused_pipe_kernel (serial wave alone on its SIMD, four-symbol FIR lanes) are 2 %
      * ahead; above that the filter is the limit and rx_pipe2_kernel's 32-frame workgroups win by 20 % */
     const int pipe_v = tuned(c->tune.pipe_v, nframes > 16 * c->ncu ? 2 : 1);
-    if (pipe_ok && pipe_v == 2) {
-        /* rx_pipe2_kernel: up to 32 frames per workgroup, one workgroup per CU when the batch allows it */
+    /* the pipeline kernels of rounds 1-2 (and the generic chunked kernel): any shape */
+    auto launch_general = [&](const FusedArgs &a, int nframes, int pv) -> int {
+        if (pipe_ok && pv == 2) {
+            /* rx_pipe2_kernel: up to 32 frames per workgroup, one workgroup per CU when the batch allows it */
+            int G = (nframes + c->ncu - 1) / c->ncu;
+            if (G > pipe2_max_frames()) G = pipe2_max_frames();
+            G = tuned(c->tune.pipe_g, G);
+            if (G > pipe2_max_frames()) G = pipe2_max_frames();
+            if (G * nbw > 64) G = 64 / nbw;
+            if (G < 1) G = 1;
+            /* wave layout: the library's (pipe2_default_layout), or the caller's for measurements: 4 bits per hardware wave
+             * = units it owns, waves 1-5 in QPSK_PIPE_LAYOUT_LO, 6-11 in QPSK_PIPE_LAYOUT_HI (their sum fixes G's units) */
+            unsigned long long layout = 0;
+            if (c->tune.layout_lo >= 0 || c->tune.layout_hi >= 0) {
+                layout = ((unsigned long long)(unsigned)tuned(c->tune.layout_lo, 0) << 4) |
+                         ((unsigned long long)(unsigned)tuned(c->tune.layout_hi, 0) << 24);
+                int units = 0, nwin = 0;
+                for (int w = 1; w < 16; w++) { const int cw = (int)((layout >> (4 * w)) & 15); units += cw; nwin += cw != 0; }
+                if (units < 1 || (G + 1) / 2 != units || pipe2_lds_bytes(G, nwin, nbw) > (size_t)MAX_LDS_BYTES)
+                    return fail(QPSK_ERR_ARG, "QPSK_PIPE_LAYOUT_*: %d units on %d waves do not match %d frames per workgroup", units, nwin, G);
+            } else {
+                for (;;) {   /* many loops per frame: the record rings grow, fewer frames fit */
+                    layout = pipe2_default_layout((G + 1) / 2);
+                    int nwin = 0;
+                    for (int w = 1; w < 16; w++) nwin += ((layout >> (4 * w)) & 15) != 0;
+                    if (layout && pipe2_lds_bytes(G, nwin, nbw) <= (size_t)MAX_LDS_BYTES) break;
+                    if (G == 1) return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: %d loops per frame", nbw);
+                    G--;
+                }
+            }
+            KERNEL_TRY(launch_rx_pipe2(a, G, layout, c->d_status, c->stream));
+            c->last_kernel = "rx_pipe2_kernel";
+        } else if (pipe_ok) {
+            /* 16-frame workgroups (four FIR waves of four frames, fewer when the batch gives a CU fewer frames); a batch
+             * above 16 frames per CU would run them in rounds */
+            auto fits = [&](int nf_) {   /* one lane of the serial wave per (frame, loop); rings grow with the loops */
+                return pipe_frames(nf_) * nbw <= 64 && pipe_lds_bytes(nf_, nbw) <= (size_t)MAX_LDS_BYTES;
+            };
+            const int full = pipe_max_nf();
+            int nf = 1;
+            while (nf < full && (long long)c->ncu * pipe_frames(nf) < nframes) nf++;
+            nf = tuned(c->tune.pipe_nf, nf);
+            if (nf < 1) nf = 1;
+            if (nf > full) nf = full;
+            while (nf > 1 && !fits(nf)) nf--;
+            if (!fits(nf))
+                return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame", nf, nbw);
+            KERNEL_TRY(launch_rx_fused_pipe(a, nf, c->d_status, c->stream));
+            c->last_kernel = "rx_fused_pipe_kernel";
+        } else {
+            KERNEL_TRY(launch_rx_fused(a, c->stream));
+            c->last_kernel = "rx_fused_kernel";
+        }
+        return QPSK_OK;
+    };
+    /* rx_lean_kernel (the FIR waves' chunk loop as one hand-written stream) serves whole even workgroups of frames made of
+     * whole chunks, one loop per frame, symmetric filter, no costas_frame[] dump; a batch's last partial workgroup and every
+     * other shape go to the kernels above.  QPSK_PIPE_V = 3 asks for it at any batch size, 1 / 2 for the older kernels. */
+    bool served = false;
+    if (pipe_ok && c->taps_symmetric && (pipe_v == 3 || c->tune.pipe_v < 0)) {
         int G = (nframes + c->ncu - 1) / c->ncu;
-        if (G > pipe2_max_frames()) G = pipe2_max_frames();
         G = tuned(c->tune.pipe_g, G);
         if (G > pipe2_max_frames()) G = pipe2_max_frames();
-        if (G * nbw > 64) G = 64 / nbw;
-        if (G < 1) G = 1;
-        /* wave layout: the library's (pipe2_default_layout), or the caller's for measurements: 4 bits per hardware wave
-         * = units it owns, waves 1-5 in QPSK_PIPE_LAYOUT_LO, 6-11 in QPSK_PIPE_LAYOUT_HI (their sum fixes G's units) */
+        G += G & 1;
+        const bool wanted = pipe_v == 3 || G > 16;      /* up to 16 frames per CU the serial wave decides: rx_fused_pipe_kernel */
         unsigned long long layout = 0;
-        if (c->tune.layout_lo >= 0 || c->tune.layout_hi >= 0) {
+        if (c->tune.layout_lo >= 0 || c->tune.layout_hi >= 0)
             layout = ((unsigned long long)(unsigned)tuned(c->tune.layout_lo, 0) << 4) |
                      ((unsigned long long)(unsigned)tuned(c->tune.layout_hi, 0) << 24);
-            int units = 0, nwin = 0;
+        else if (G >= 2)
+            layout = pipe2_default_layout(G / 2);
+        FusedArgs am = a;
+        am.nframes = nframes - nframes % (G > 0 ? G : 1);
+        if (wanted && layout && am.nframes > 0 && lean_shape_ok(am, G)) {
+            int nwin = 0, units = 0;
             for (int w = 1; w < 16; w++) { const int cw = (int)((layout >> (4 * w)) & 15); units += cw; nwin += cw != 0; }
-            if (units < 1 || (G + 1) / 2 != units || pipe2_lds_bytes(G, nwin, nbw) > (size_t)MAX_LDS_BYTES)
-                return fail(QPSK_ERR_ARG, "QPSK_PIPE_LAYOUT_*: %d units on %d waves do not match %d frames per workgroup", units, nwin, G);
-        } else {
-            for (;;) {   /* many loops per frame: the record rings grow, fewer frames fit */
-                layout = pipe2_default_layout((G + 1) / 2);
-                int nwin = 0;
-                for (int w = 1; w < 16; w++) nwin += ((layout >> (4 * w)) & 15) != 0;
-                if (layout && pipe2_lds_bytes(G, nwin, nbw) <= (size_t)MAX_LDS_BYTES) break;
-                if (G == 1) return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: %d loops per frame", nbw);
-                G--;
+            if (units == G / 2 && lean_lds_bytes(G, nwin) <= (size_t)MAX_LDS_BYTES) {
+                KERNEL_TRY(launch_rx_lean(am, G, layout, c->d_status, c->stream));
+                c->last_kernel = "rx_lean_kernel";
+                served = true;
+                const int rem = nframes - am.nframes;
+                if (rem > 0) {      /* the last partial workgroup */
+                    FusedArgs ar = a;
+                    const size_t o = (size_t)am.nframes;
+                    ar.nframes = rem;
+                    ar.x += o * (size_t)a.frame_size;
+                    if (ar.index) ar.index += o;
+                    ar.sym += o * (size_t)a.nsym;
+                    if (ar.freq) ar.freq += o;
+                    if (ar.phase) ar.phase += o;
+                    if (ar.hz) ar.hz += o;
+                    const char *lk = c->last_kernel;
+                    int rc2 = launch_general(ar, rem, rem > 16 * c->ncu ? 2 : 1);
+                    if (rc2) return rc2;
+                    c->last_kernel = lk;
+                }
             }
         }
-        KERNEL_TRY(launch_rx_pipe2(a, G, layout, c->d_status, c->stream));
-        c->last_kernel = "rx_pipe2_kernel";
-    } else if (pipe_ok) {
-        /* 16-frame workgroups (four FIR waves of four frames, fewer when the batch gives a CU fewer frames); a batch
-         * above 16 frames per CU would run them in rounds */
-        auto fits = [&](int nf_) {   /* one lane of the serial wave per (frame, loop); rings grow with the loops */
-            return pipe_frames(nf_) * nbw <= 64 && pipe_lds_bytes(nf_, nbw) <= (size_t)MAX_LDS_BYTES;
-        };
-        const int full = pipe_max_nf();
-        int nf = 1;
-        while (nf < full && (long long)c->ncu * pipe_frames(nf) < nframes) nf++;
-        nf = tuned(c->tune.pipe_nf, nf);
-        if (nf < 1) nf = 1;
-        if (nf > full) nf = full;
-        while (nf > 1 && !fits(nf)) nf--;
-        if (!fits(nf))
-            return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame", nf, nbw);
-        KERNEL_TRY(launch_rx_fused_pipe(a, nf, c->d_status, c->stream));
-        c->last_kernel = "rx_fused_pipe_kernel";
-    } else {
-        KERNEL_TRY(launch_rx_fused(a, c->stream));
-        c->last_kernel = "rx_fused_kernel";
+    }
+    if (!served) {
+        int rc2 = launch_general(a, nframes, pipe_v == 3 ? (nframes > 16 * c->ncu ? 2 : 1) : pipe_v);
+        if (rc2) return rc2;
     }
     if (d_index) {
         if (idx)

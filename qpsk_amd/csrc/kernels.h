@@ -72,6 +72,10 @@ int pipe2_max_units_per_wave(void);
 int pipe2_max_hw_waves(void);
 unsigned long long pipe2_default_layout(int NU);        /* 4 bits per hardware wave: units it owns; 0 if NU does not fit */
 int launch_rx_pipe2(const FusedArgs &a, int G, unsigned long long layout, int *status, hipStream_t s);
+/* rx_fused.hip: the same pipeline with the FIR waves' chunk loop as one hand-written stream (fir_lean_asm.h) */
+size_t lean_lds_bytes(int G, int nwin);
+bool lean_shape_ok(const FusedArgs &a, int G);          /* one loop per frame, whole chunks, whole even workgroups, ... */
+int launch_rx_lean(const FusedArgs &a, int G, unsigned long long layout, int *status, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s);
 int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s);

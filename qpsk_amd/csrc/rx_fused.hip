@@ -46,6 +46,7 @@
 #include "costas_asm.h"
 #include "fir_r2_asm.h"
 #include "fir_r4_asm.h"
+#include "fir_lean_asm.h"
 #include "kernels.h"
 
 #ifndef QPSK_PIPE1_ASM
@@ -1304,6 +1305,174 @@ int launch_rx_pipe2(const FusedArgs &a0, int G, unsigned long long layout, int *
     return (int)hipGetLastError();
 }
 
+/* ========================================================================
+ * rx_lean_kernel: rx_pipe2_kernel's pipeline (two-frame units, per-wave windows, the same rings, counters and serial
+ * wave) with the FIR waves' WHOLE chunk loop as one hand-written instruction stream (fir_lean_asm.h, generated by
+ * tools/gen_lean_asm.py): ~600 vector instructions per unit and chunk where the compiler's version of the same work
+ * issued 700-800 (508 are the filter), the 64 distinct taps of the symmetric filter in SGPRs (no tap reads: a third
+ * of the LDS instructions gone), no fence anywhere -- a hand-over is two LDS writes in program order, so a wave never
+ * waits for its symbol stores or for the prefetched samples of its next unit -- and one counted vmcnt wait per unit.
+ * What it serves (launch_rx_lean checks; everything else stays with the kernels above): CYCLES = 8, frames of whole
+ * 64-symbol chunks (at least two), one loop per frame from a fresh state, no costas_frame[] dump, a symmetric filter,
+ * 16-byte aligned frames, whole workgroups of an even number of frames.  Results: the same bits.
+ * ======================================================================== */
+namespace lean {
+constexpr int PRM_DWORDS = 20;                        /* per-wave parameter block of the stream */
+constexpr int HW_WAVES = pipe2::MAX_THREADS / 64;
+struct SmemLean {
+    Smem s;                                           /* taps[] unused here: the stream keeps the taps in SGPRs */
+    unsigned prm[HW_WAVES][PRM_DWORDS];
+};
+static_assert(sizeof(SmemLean) % 16 == 0 && offsetof(Smem, ready) == 512 && offsetof(Smem, consumed) == 576 &&
+              offsetof(Smem, abort_flag) == 580, "fir_lean_asm.h addresses the counters by these offsets");
+static_assert(FIR_LEAN_END_VGPR <= 168, "three waves per SIMD");
+} // namespace lean
+
+template <int NUW>
+__device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::SmemLean *sl, float2 *mywin, float2 *dring,
+                                              float *zring, int hwave, int u0, int f0, int lane, int nchunks, int *status)
+{
+    using namespace pipe2;
+    using GM = GeomNarrow;
+    Smem *sm = &sl->s;
+    const int L = a.frame_size, N = a.nsym;
+    const int fl = lane / QL, q = lane % QL;
+    const bool simd0 = (hwave & 3) == 0;                 /* placed beside the serial wave (layout): keeps priority 3 */
+    unsigned *prm = sl->prm[hwave];
+    unsigned ixpack = ((unsigned)(4 * u0) << 16) | (simd0 && !(a.dbg & 1024) ? 0x80000000u : 0u);
+    LeanLaneAddr w;
+#pragma unroll
+    for (int ui = 0; ui < 2; ui++) {
+        const int u = u0 + (ui < NUW ? ui : 0);
+#pragma unroll
+        for (int ff = 0; ff < UF; ff++) {
+            const int fr = f0 + UF * u + ff;
+            const int ix = __builtin_amdgcn_readfirstlane(a.index ? a.index[fr] : a.fixed_index) & 7;   /* decimation offset, < C */
+            if (ui < NUW) ixpack |= (unsigned)ix << (4 * (2 * ui + ff));
+            const int p0 = 2 * lane + HIST - ix;          /* window position of sample 2*lane of a chunk */
+            w.wr0[ui][ff] = lds_addr(mywin + ff * WS + slot_of(p0)) - 8u * BLK;
+            w.wr1[ui][ff] = lds_addr(mywin + ff * WS + slot_of(p0 + 1)) - 8u * BLK;
+            if (lane == 0) {
+                const unsigned long long src = (unsigned long long)(a.x + (size_t)fr * L);
+                prm[4 * ui + 2 * ff] = (unsigned)src;
+                prm[4 * ui + 2 * ff + 1] = (unsigned)(src >> 32);
+            }
+        }
+        const int g = UF * u + fl;
+        w.ring[ui] = lds_addr(dring + (size_t)g * GM::DSTRIDE + R * q);
+        w.z[ui] = lds_addr(zring + (size_t)g * GM::ZSTRIDE + R * q);
+        if (lane == 0) {
+            const unsigned long long sb = (unsigned long long)(a.sym + (size_t)(f0 + UF * u) * N);
+            prm[8 + 2 * ui] = (unsigned)sb;
+            prm[8 + 2 * ui + 1] = (unsigned)(sb >> 32);
+        }
+    }
+    if (lane == 0) {
+        prm[12] = (unsigned)nchunks;
+        prm[13] = ixpack;
+        prm[16] = (unsigned)(unsigned long long)a.taps;
+        prm[17] = (unsigned)((unsigned long long)a.taps >> 32);
+    }
+    if (simd0 && !(a.dbg & 1024)) __builtin_amdgcn_s_setprio(3);
+    const unsigned rd = lds_addr(mywin + fl * WS + (PAD + PADS) * q);
+    int st;
+    if constexpr (NUW == 2)
+        st = fir_lean_loop2(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w);
+    else
+        st = fir_lean_loop1(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w);
+    bool ok = st == 0;
+    if (ok) {
+        ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
+        if (ok)
+#pragma unroll
+            for (int ui = 0; ui < NUW; ui++) {
+                const int g = UF * (u0 + ui) + fl;
+                for (int c = nchunks - DR; c < nchunks; c++)
+                    flush_records<GM, R>(a, zring, dring, g, f0 + g, q, c);
+            }
+    } else if (lane == 0) {
+        __hip_atomic_store(&sm->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (!ok && lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
+}
+
+__global__ void __launch_bounds__(pipe2::MAX_THREADS)
+rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
+{
+    using namespace pipe2;
+    using GM = GeomNarrow;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    lean::SmemLean *sl = reinterpret_cast<lean::SmemLean *>(smem_raw);
+    Smem *sm = &sl->s;
+    const int G = a.G;
+    float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(lean::SmemLean));   /* [nwin][UF][WS] */
+    float2 *dring = win + (size_t)nwin * UF * WS;                                    /* [G][DSTRIDE] */
+    float *zring = reinterpret_cast<float *>(dring + (size_t)G * GM::DSTRIDE);       /* [G][ZSTRIDE] */
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f0 = blockIdx.x * G;
+    const int nchunks = a.nsym / S;
+
+    if (tid < MAX_WAVES) sm->ready[tid] = 0;
+    if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
+    __syncthreads();
+
+    if (wave == 0) {
+        costas_wave<GM>(a, sm, dring, zring, G, f0, lane, nchunks, status);   /* a.mixed == 2: lane g waits on ready[g / 2] */
+        return;
+    }
+    const int mine = (int)((layout >> (4 * wave)) & 15);
+    if (mine == 0) return;
+    int u0 = 0, widx = 0;
+    for (int v = 1; v < wave; v++) {
+        const int cv = (int)((layout >> (4 * v)) & 15);
+        u0 += cv;
+        widx += cv != 0;
+    }
+    float2 *mywin = win + (size_t)widx * UF * WS;
+    if (mine == 2)
+        fir_wave_lean<2>(a, sl, mywin, dring, zring, wave, u0, f0, lane, nchunks, status);
+    else
+        fir_wave_lean<1>(a, sl, mywin, dring, zring, wave, u0, f0, lane, nchunks, status);
+}
+
+size_t lean_lds_bytes(int G, int nwin)
+{
+    using GM = GeomNarrow;
+    size_t b = sizeof(lean::SmemLean) + sizeof(float2) * ((size_t)nwin * pipe2::UF * pipe2::WS + (size_t)G * GM::DSTRIDE) +
+               sizeof(float) * (size_t)G * GM::ZSTRIDE;
+    return (b + 15) & ~(size_t)15;
+}
+
+/* what rx_lean_kernel serves (see its header); the caller has checked CYCLES = 8, the alignment and the filter's symmetry */
+bool lean_shape_ok(const FusedArgs &a, int G)
+{
+    return a.nbw == 1 && !a.costas && !a.state_in && !a.state_out && a.nsym % pipe2::S == 0 && a.nsym >= 2 * pipe2::S &&
+           a.frame_size == a.nsym * C && G >= 2 && G % 2 == 0 && G <= pipe2::UF * pipe2::MAX_UNITS && a.nframes % G == 0 &&
+           !(a.dbg & (8 | 16));
+}
+
+int launch_rx_lean(const FusedArgs &a0, int G, unsigned long long layout, int *status, hipStream_t s)
+{
+    using namespace pipe2;
+    FusedArgs a = a0;
+    int units = 0, nwin = 0, hw = 1;
+    for (int w = 1; w < 16; w++) {
+        const int cw = (int)((layout >> (4 * w)) & 15);
+        if (cw > 2 || (cw && w >= MAX_THREADS / 64)) return (int)hipErrorInvalidValue;
+        units += cw;
+        nwin += cw != 0;
+        if (cw) hw = w + 1;
+    }
+    if (!lean_shape_ok(a, G) || units != G / UF || (layout & 15) || lean_lds_bytes(G, nwin) > (size_t)MAX_LDS_BYTES)
+        return (int)hipErrorInvalidValue;
+    a.G = G;
+    a.mixed = 2;
+    a.share_simd0 = ((layout >> 16) & 15) != 0 || ((layout >> 32) & 15) != 0;
+    hipLaunchKernelGGL(rx_lean_kernel, dim3(a.nframes / G), dim3(64 * hw), lean_lds_bytes(G, nwin), s, a, layout, nwin, status);
+    return (int)hipGetLastError();
+}
+
 /* frames of a workgroup with NF FIR waves */
 template <class GM>
 static int frames_of(int NF)
@@ -1368,6 +1537,9 @@ int prepare_pipe_kernel(void)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_pipe2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_lean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(rx_fused_pipe_kernel<GeomNarrow>),

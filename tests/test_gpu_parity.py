@@ -177,6 +177,62 @@ def test_pipeline_geometries_agree(oracle, L, mode):
     assert_batch_equal(got, want)
 
 
+@pytest.mark.parametrize("L,mode,index", [(2048, TIMING_FIXED, 6), (1024, TIMING_FIXED, 3), (4096, TIMING_FIXED, 7),
+                                          (2048, TIMING_HIST, 0), (16384, TIMING_FIXED, 0)])
+def test_lean_kernel_equals_oracle(oracle, L, mode, index):
+    """rx_lean_kernel (the FIR waves' whole chunk loop as one hand-written stream, taps in SGPRs): the oracle's bits
+    for every even workgroup size, for explicit wave layouts (one and two units per wave, a FIR wave beside the serial
+    wave), even, odd and per-frame decimation offsets (histogram timing), all-zero frames, and batches whose last
+    partial workgroup goes to the older kernels"""
+    fs, rs, F = 19200.0, 2400.0, 77
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=mode, fixed_index=index)
+    x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=L + index, noise=0.05)
+    x[7] = 0.0
+    x[40, : L // 2] = 0.0
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=mode, fixed_index=index)
+    m.tune(pipe_v=3)
+    for G in (2, 4, 6, 10, 16, 18, 30, 32):
+        m.tune(pipe_g=G)
+        for n in (F, F - F % G, G):
+            got = m.rx_batch(x[:n])
+            m.sync()
+            assert m.last_kernel() == "rx_lean_kernel", (G, n, m.last_kernel())
+            for k in ("sym", "phase", "freq", "hz", "index"):
+                assert bits_equal(cpu(got[k]), want[k][:n].astype(cpu(got[k]).dtype)), (k, G, n)
+    for G, lo, hi in ((4, 0x00002, 0), (6, 0x01011, 0), (10, 0x11111, 0), (32, 0x22222, 0x011022), (32, 0x20222, 0x112022),
+                      (24, 0x20222, 0x000022), (32, 0x21222, 0x012022)):
+        m.tune(pipe_g=G, pipe_layout_lo=lo, pipe_layout_hi=hi)
+        got = m.rx_batch(x)
+        m.sync()
+        assert m.last_kernel() == "rx_lean_kernel", (G, lo, hi)
+        for k in ("sym", "phase", "freq", "hz"):
+            assert bits_equal(cpu(got[k]), want[k]), (k, G, hex(lo), hex(hi))
+    # shapes it does not serve stay with the other kernels: a costas_frame[] dump, an odd workgroup
+    m.tune(pipe_layout_lo=None, pipe_layout_hi=None, pipe_g=32)
+    got = m.rx_batch(x, want_costas=True)
+    m.sync()
+    assert m.last_kernel() != "rx_lean_kernel"
+    assert_batch_equal(got, oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=mode, fixed_index=index, want_costas=True))
+
+
+def test_lean_kernel_wraps_and_loop_variants(oracle):
+    """carrier offsets that wrap the phase every few symbols, a wide clamp and an asymmetric one (the serial wave's
+    fallbacks) through rx_lean_kernel"""
+    fs, rs, L, F = 19200.0, 2400.0, 4096, 64
+    for offset_hz, bw, lim in ((270.0, np.float32(0.6), (-1.0, 1.0)), (-250.0, np.float32(0.3), (-7.0, 7.0)),
+                               (120.0, BW, (0.0, 1.0))):
+        m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6, loop_bw=bw, min_freq=lim[0],
+                  max_freq=lim[1])
+        x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=offset_hz, base_seed=int(abs(offset_hz)), noise=0.1)
+        want = oracle.rx_batch(x, fs, rs, loop_bw=bw, min_freq=lim[0], max_freq=lim[1], timing_mode=TIMING_FIXED, fixed_index=6)
+        m.tune(pipe_v=3, pipe_g=32)
+        got = m.rx_batch(x)
+        m.sync()
+        assert m.last_kernel() == "rx_lean_kernel"
+        for k in ("sym", "phase", "freq", "hz"):
+            assert bits_equal(cpu(got[k]), want[k]), (k, offset_hz)
+
+
 def test_rx_batch_golden_vectors():
     """straight against the reference's own outputs (tests/golden, generated from the reference)"""
     for name in ("c1small", "c1", "c5small_bw200"):

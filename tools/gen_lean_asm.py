@@ -1,0 +1,485 @@
+#!/usr/bin/env python3
+"""Generator of qpsk_amd/csrc/fir_lean_asm.h: the WHOLE chunk loop of a FIR wave of rx_lean_kernel (rx_fused.hip) as
+one gfx950 instruction stream per wave shape (1 or 2 two-frame units per wave).
+
+    python tools/gen_lean_asm.py > qpsk_amd/csrc/fir_lean_asm.h
+
+What one iteration of the loop does for one unit (2 frames x 64 symbols of chunk c; reference rrc_fir.c:17-30 evaluated at
+the samples qpsk.c:190 keeps, then the slicer of qpsk.c:74-79 on the loop's de-rotated symbols, qpsk.c:197):
+  stage     the unit's 1024 prefetched samples + 2 x 126 samples of history (the owner's registers) -> the wave's LDS
+            window (ds_write_b128; two ds_write_b64 per pair when the frame's decimation offset is odd);
+  prefetch  the next unit's samples: 8 global_load_dwordx4 (SGPR base + lane offset + immediate), a whole unit ahead;
+  filter    254 + 254 packed multiplies / adds per lane (2 symbols), taps 0..126 in order, unfused, into one (re, im)
+            accumulator per symbol; the 64 distinct taps of the (symmetric) RRC filter sit in SGPRs s36..s99 for the
+            whole kernel -- no tap reads, no tap registers; window pairs come one block of 8 positions ahead
+            (ds_read_b128, counted lgkmcnt waits);
+  gain      y * GAIN in double, narrowed (rrc_fir.c:28);
+  flush     of chunk c - 2, once the loop has consumed it: sin/cos of the recorded phase again (the library's
+            polynomials, Horner form), T = d x conj(C + jS) exactly as the loop formed it, (T.x, T.y) * ROT45, sum and
+            difference, then the quadrant of the phase selects and signs them (bits[0] = Re < 0, bits[1] = Im < 0 of
+            qpsk.c:77-78 on the rotated symbol -- exact, including the zeros); one 2-byte store per lane;
+  hand-over the unit's 128 new symbols -> the symbol ring, then ready[unit] = c + 1 (LDS executes a wave's operations in
+            order: no fence, and in particular no wait for the global stores and loads in flight).
+Synchronisation with the serial wave: `consumed` (and the workgroup's abort flag beside it) polled with bounded spins.
+
+The kernel-side contract (what rx_lean_kernel sets up) is in the generated header's comment.
+"""
+import sys
+
+NTAPS, C = 127, 8
+R, STEP = 2, 8
+TSTEPS = NTAPS + STEP * (R - 1)        # 135 window positions per lane
+NB = (TSTEPS + C - 1) // C
+PAD = R * STEP
+BLK_BYTES = (128 + 2 * (128 // PAD)) * 8   # one 128-sample block of the padded window image: 1152 bytes
+DEPTH = 1
+NW = DEPTH + 1
+
+# ---- fixed registers of the block
+PRE = 32            # v32..v63   prefetched samples: frame ff, load j -> PRE + 16 ff + 4 j (4 dwords each)
+HIST = 64           # v64..v79   history: unit ui, frame ff -> HIST + 8 ui + 4 ff
+ACC = 80            # v80:81, v82:83
+G = 84              # v84..v87   the unit's two symbols after the gain (one ds_write_b128)
+TMP = 88            # v88..v91
+CONST = 92          # v92..v113  eleven fp64 constants
+K2PI, HPI, C4, S3, C2, S1, C1, MAGIC, C3, S2, GAIN = [CONST + 2 * i for i in range(11)]
+P0 = 114            # v114..v121 products
+W0 = 122            # v122..v153 window blocks
+FL = 114            # flush temporaries v114..v159 (the filter's registers are free by then)
+VLAST = 159
+TAP0 = 36           # s36..s99: taps 0..63 (s_load_dwordx16 wants a multiple of 4; s100, s101 are reserved)
+# SGPRs s10..s31, s35 (s32..s34 are the ABI's stack / frame / base pointers: left alone)
+SRC = 10            # s10..s17   source pointers unit ui, frame ff -> SRC + 4 ui + 2 ff
+SYMB = 18           # s18..s21   symbol store bases per unit
+SC, SN, SPR, SSPIN, ST0, ST1, ST2, ST3, SIX, SFL, SCONS = 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 35
+SPIN_LIMIT = 1 << 24
+
+CONSTS = {   # name -> (register, double as hex bits)
+    K2PI: 0x3FE45F306DC9C883, HPI: 0x3FF921FB54442D18, C4: 0x3EF99343027BF8C3, S3: 0xBF2994EB3774CF24,
+    C2: 0x3FA55553E1068F19, S1: 0xBFC555545995A603, C1: 0xBFDFFFFFFD0C621C, MAGIC: 0x4338000000000000,
+    C3: 0xBF56C087E89A359D, S2: 0x3F81107605230BC4, GAIN: 0x3FFD99999999999A,
+}
+ROT45 = 0x3F3504F3   # 0x1.6a09e6p-1f
+
+
+def vp(r):
+    return "v[%d:%d]" % (r, r + 1)
+
+
+def v4(r):
+    return "v[%d:%d]" % (r, r + 3)
+
+
+def sp(r):
+    return "s[%d:%d]" % (r, r + 1)
+
+
+def slot_of(p):
+    return p + 2 * (p // PAD)
+
+
+class Emit:
+    def __init__(self):
+        self.lines = []
+        self.nlabel = 0
+
+    def __call__(self, fmt, *a):
+        self.lines.append((fmt % a) if a else fmt)
+
+    def label(self, stem):
+        self.nlabel += 1
+        return "L%s%d_%%=" % (stem, self.nlabel)
+
+    def place(self, lab):
+        self.lines.append(lab + ":")
+
+
+def tap_operand(k):
+    """SGPR pair and op_sel text that broadcast tap k to both halves of a packed multiply (tap = src0)"""
+    uk = k if k <= 63 else 126 - k          # the filter is symmetric: checked by the host before this kernel is chosen
+    r = TAP0 + uk
+    if r % 2 == 0:
+        return sp(r), "op_sel_hi:[0,1]"
+    return sp(r - 1), "op_sel:[1,0]"
+
+
+def wreg(t):
+    b, u = divmod(t, C)
+    return vp(W0 + 16 * (b % NW) + 2 * u)
+
+
+def fetch(e, b):
+    n = 0
+    for u in range(0, C, 2):
+        t = b * C + u
+        if t < TSTEPS:
+            r = W0 + 16 * (b % NW) + 2 * u
+            e("ds_read_b128 %s, %%[rd] offset:%d", v4(r), 8 * slot_of(t))
+            n += 1
+    return n
+
+
+def filter_stream(e):
+    """the sum of fir_r2_asm.h (tools/gen_fir_asm.py) with the taps as SGPR operands"""
+    reads = {}
+    for d in range(min(DEPTH, NB)):
+        reads[d] = fetch(e, d)
+    e("v_mov_b64 %s, 0", vp(ACC))
+    e("v_mov_b64 %s, 0", vp(ACC + 2))
+    acc = [vp(ACC), vp(ACC + 2)]
+    nmul = 0
+    for b in range(NB):
+        if b + DEPTH < NB:
+            reads[b + DEPTH] = fetch(e, b + DEPTH)
+        later = sum(reads.get(x, 0) for x in range(b + 1, min(NB, b + DEPTH + 1)))
+        e("s_waitcnt lgkmcnt(%d)", later)
+        for u in range(0, C, 2):
+            muls, adds = [], []
+            np_ = 0
+            for t in (b * C + u, b * C + u + 1):
+                if t >= TSTEPS:
+                    continue
+                for sym in range(R):
+                    k = t - STEP * sym
+                    if 0 <= k < NTAPS:
+                        treg, sel = tap_operand(k)
+                        p = vp(P0 + 2 * np_)
+                        muls.append("v_pk_mul_f32 %s, %s, %s %s" % (p, treg, wreg(t), sel))
+                        adds.append("v_pk_add_f32 %s, %s, %s" % (acc[sym], acc[sym], p))
+                        np_ += 1
+                        nmul += 1
+            for x in muls + adds:
+                e(x)
+    assert nmul == 254
+    return nmul
+
+
+def stage_frame(e, ui, ff):
+    """history + the four prefetched blocks of frame ff -> the window (even offset: one 16-byte word per pair)"""
+    sh = 4 * (2 * ui + ff)
+    wr0, wr1 = "%%[w0_%d%d]" % (ui, ff), "%%[w1_%d%d]" % (ui, ff)
+    hist = HIST + 8 * ui + 4 * ff
+    odd, done = e.label("odd"), e.label("stg")
+    e("s_bfe_u32 s%d, s%d, 0x4%04x", ST0, SIX, sh)             # the frame's decimation offset
+    e("s_lshr_b32 s%d, s%d, 1", ST1, ST0)
+    e("s_add_u32 s%d, s%d, 1", ST1, ST1)                         # lanes below (ix >> 1) + 1 hold no history of their own
+    e("s_lshl_b64 %s, -1, s%d", sp(ST2), ST1)
+    e("s_bitcmp1_b32 s%d, 0", ST0)
+    e("s_cbranch_scc1 %s", odd)
+    e("s_mov_b64 exec, %s", sp(ST2))
+    e("ds_write_b128 %s, %s", wr0, v4(hist))
+    e("s_mov_b64 exec, -1")
+    for j in range(4):
+        e("ds_write_b128 %s, %s offset:%d", wr0, v4(PRE + 16 * ff + 4 * j), (j + 1) * BLK_BYTES)
+    e("s_branch %s", done)
+    e.place(odd)
+    e("s_mov_b64 exec, %s", sp(ST2))
+    e("ds_write_b64 %s, %s", wr1, vp(hist + 2))
+    e("s_lshl_b64 %s, %s, 1", sp(ST2), sp(ST2))                  # the pair's first sample: one lane more
+    e("s_mov_b64 exec, %s", sp(ST2))
+    e("ds_write_b64 %s, %s", wr0, vp(hist))
+    e("s_mov_b64 exec, -1")
+    for j in range(4):
+        r = PRE + 16 * ff + 4 * j
+        e("ds_write_b64 %s, %s offset:%d", wr0, vp(r), (j + 1) * BLK_BYTES)
+        e("ds_write_b64 %s, %s offset:%d", wr1, vp(r + 2), (j + 1) * BLK_BYTES)
+    e.place(done)
+    r = PRE + 16 * ff + 12
+    e("v_mov_b64 %s, %s", vp(hist), vp(r))
+    e("v_mov_b64 %s, %s", vp(hist + 2), vp(r + 2))
+
+
+def loads(e, u):
+    for ff in range(2):
+        for j in range(4):
+            e("global_load_dwordx4 %s, %%[voff], %s offset:%d", v4(PRE + 16 * ff + 4 * j), sp(SRC + 4 * u + 2 * ff), 1024 * j)
+    for ff in range(2):
+        s = SRC + 4 * u + 2 * ff
+        e("s_add_u32 s%d, s%d, 0x1000", s, s)
+        e("s_addc_u32 s%d, s%d, 0", s + 1, s + 1)
+
+
+def sincos_pair(e, ph, b):
+    """raw polynomial values of sin/cos(ph) (sincos_raw_horner, sincos_f32.h) for two symbols at once: ph[k] -> C in
+    b[k]+8, S in b[k]+10 (floats), n in b[k]+2.  Register use per symbol, from base b: X 0:1, M 2:3, N/X3 12:13,
+    XR 4:5, X2 6:7, C 8:9, S 10:11."""
+    def both(fmt):
+        for k in range(2):
+            B = b[k]
+            e(fmt.format(X=vp(B), M=vp(B + 2), XR=vp(B + 4), X2=vp(B + 6), C=vp(B + 8), S=vp(B + 10), N=vp(B + 12),
+                         PH="v%d" % ph[k], Cf="v%d" % (B + 8), Sf="v%d" % (B + 10),
+                         K2PI=vp(K2PI), HPI=vp(HPI), C4=vp(C4), S3=vp(S3), C2=vp(C2), S1=vp(S1), C1=vp(C1), MAGIC=vp(MAGIC),
+                         C3=vp(C3), S2=vp(S2)))
+    both("v_cvt_f64_f32 {X}, {PH}")
+    both("v_fma_f64 {M}, {X}, {K2PI}, {MAGIC}")
+    both("v_add_f64 {N}, {M}, -{MAGIC}")
+    both("v_fma_f64 {XR}, -{N}, {HPI}, {X}")
+    both("v_mul_f64 {X2}, {XR}, {XR}")
+    both("v_fma_f64 {C}, {X2}, {C4}, {C3}")
+    both("v_fma_f64 {S}, {X2}, {S3}, {S2}")
+    both("v_fma_f64 {C}, {X2}, {C}, {C2}")
+    both("v_mul_f64 {N}, {XR}, {X2}")              # x^3 (N is dead)
+    both("v_fma_f64 {C}, {X2}, {C}, {C1}")
+    both("v_fma_f64 {S}, {X2}, {S}, {S1}")
+    both("v_fma_f64 {C}, {X2}, {C}, 1.0")
+    both("v_fma_f64 {S}, {N}, {S}, {XR}")
+    both("v_cvt_f32_f64 {Cf}, {C}")
+    both("v_cvt_f32_f64 {Sf}, {S}")
+
+
+def flush(e, ui):
+    """symbols of chunk c - 2 of this lane's frame: records (phases) v[FL:FL+1], symbols v[FL+2:FL+5]"""
+    PH = [FL, FL + 1]
+    D = [FL + 2, FL + 4]
+    b = [FL + 6, FL + 26]            # 20 registers per symbol
+    e("ds_read_b64 %s, v%d", vp(FL), TMP + 3)
+    e("ds_read_b128 %s, v%d", v4(FL + 2), TMP + 2)
+    e("s_waitcnt lgkmcnt(0)")
+    sincos_pair(e, PH, b)
+    for k in range(2):
+        B = b[k]
+        d = vp(D[k])
+        # T = d x conj(C + jS) as the loop formed it (costas_asm.h): (d.x C, d.y C), (d.y S, d.x S), sum with the sign
+        e("v_pk_mul_f32 %s, %s, %s op_sel_hi:[1,0]", vp(B + 14), d, vp(B + 8))
+        e("v_pk_mul_f32 %s, %s, %s op_sel:[1,0] op_sel_hi:[0,0]", vp(B + 16), d, vp(B + 10))
+    for k in range(2):
+        B = b[k]
+        e("v_pk_add_f32 %s, %s, %s neg_hi:[0,1]", vp(B + 18), vp(B + 14), vp(B + 16))
+    for k in range(2):
+        B = b[k]
+        # (T.x, T.y) * ROT45 (qpsk.c:75: both components of the rotation are the same float)
+        e("v_pk_mul_f32 %s, %s, %s op_sel_hi:[1,0]", vp(B + 14), vp(B + 18), vp(TMP))
+    for k in range(2):
+        B = b[k]
+        e("v_sub_f32_e32 v%d, v%d, v%d", B + 16, B + 14, B + 15)      # D = a - b
+        e("v_add_f32_e32 v%d, v%d, v%d", B + 17, B + 14, B + 15)      # S = a + b
+    # quadrant q = n & 3 of the phase: z = T (-j)^q, so with (rr, ri) = (zx - zy, zx + zy) R:
+    #   q: 0 (D, S)   1 (S, -D)   2 (-D, -S)   3 (-S, D)        bits[0] = rr < 0, bits[1] = ri < 0
+    for k in range(2):
+        B = b[k]
+        n = B + 2
+        e("v_and_b32_e32 v%d, 1, v%d", B + 4, n)
+        e("v_cmp_eq_u32_e32 vcc, 1, v%d", B + 4)
+        e("v_cndmask_b32_e32 v%d, v%d, v%d, vcc", B + 5, B + 16, B + 17)     # rr magnitude: q odd ? S : D
+        e("v_cndmask_b32_e32 v%d, v%d, v%d, vcc", B + 6, B + 17, B + 16)     # ri magnitude: q odd ? D : S
+        e("v_and_b32_e32 v%d, 2, v%d", B + 4, n)
+        e("v_lshl_add_u32 v%d, v%d, 30, v%d", B + 5, B + 4, B + 5)           # rr negated in quadrants 2, 3
+        e("v_add_u32_e32 v%d, 1, v%d", B + 4, n)
+        e("v_and_b32_e32 v%d, 2, v%d", B + 4, B + 4)
+        e("v_lshl_add_u32 v%d, v%d, 30, v%d", B + 6, B + 4, B + 6)           # ri negated in quadrants 1, 2
+        e("v_cmp_gt_f32_e32 vcc, 0, v%d", B + 6)
+        e("v_addc_co_u32_e64 v%d, vcc, 0, 0, vcc", B + 7)                    # bits[1]
+        e("v_cmp_gt_f32_e32 vcc, 0, v%d", B + 5)
+        e("v_addc_co_u32_e64 v%d, vcc, v%d, v%d, vcc", B + 7, B + 7, B + 7)  # (bits[1] << 1) | bits[0]
+    e("v_lshl_or_b32 v%d, v%d, 8, v%d", FL, b[1] + 7, b[0] + 7)
+    e("global_store_short %%[symoff], v%d, %s", FL, sp(SYMB + 2 * ui))
+    e("s_add_u32 s%d, s%d, 64", SYMB + 2 * ui, SYMB + 2 * ui)
+    e("s_addc_u32 s%d, s%d, 0", SYMB + 2 * ui + 1, SYMB + 2 * ui + 1)
+
+
+def unit(e, ui, nuw):
+    last = ui == nuw - 1
+    nx = (ui + 1) % nuw
+    # ---- priority by need: the fewer chunks this wave is ahead of the loop, the higher (rx_fused.hip, rx_pipe2_kernel)
+    pr_done, pr1, pr2 = e.label("pr"), e.label("pr"), e.label("pr")
+    e("ds_read_b32 v%d, %%[smem] offset:576", TMP + 1)
+    e("s_waitcnt lgkmcnt(0)")
+    e("v_readfirstlane_b32 s%d, v%d", SCONS, TMP + 1)
+    e("s_bitcmp1_b32 s%d, 31", SIX)                             # the FIR wave beside the serial wave keeps priority 3
+    e("s_cbranch_scc1 %s", pr_done)
+    e("s_sub_i32 s%d, s%d, s%d", ST0, SC, SCONS)
+    e("s_cmp_gt_i32 s%d, 0", ST0)
+    e("s_cbranch_scc1 %s", pr1)
+    e("s_setprio 2")
+    e("s_branch %s", pr_done)
+    e.place(pr1)
+    e("s_cmp_gt_i32 s%d, 1", ST0)
+    e("s_cbranch_scc1 %s", pr2)
+    e("s_setprio 1")
+    e("s_branch %s", pr_done)
+    e.place(pr2)
+    e("s_setprio 0")
+    e.place(pr_done)
+    # ---- the unit's samples: everything issued after their loads is the previous iteration's symbol store, if any
+    w1, w2 = e.label("vm"), e.label("vm")
+    e("s_cmp_eq_u32 s%d, 0", SFL)
+    e("s_cbranch_scc1 %s", w1)
+    e("s_waitcnt vmcnt(1)")
+    e("s_branch %s", w2)
+    e.place(w1)
+    e("s_waitcnt vmcnt(0)")
+    e.place(w2)
+    e("s_mov_b32 s%d, 0", SFL)
+    stage_frame(e, ui, 0)
+    stage_frame(e, ui, 1)
+    # ---- the next unit's samples, a whole unit ahead
+    if last:
+        skip = e.label("ld")
+        e("s_add_u32 s%d, s%d, 1", ST0, SC)
+        e("s_cmp_ge_u32 s%d, s%d", ST0, SN)
+        e("s_cbranch_scc1 %s", skip)
+        loads(e, nx)
+        e.place(skip)
+    else:
+        loads(e, nx)
+    # ---- filter, gain
+    filter_stream(e)
+    for i in range(4):
+        e("v_cvt_f64_f32 %s, v%d", vp(P0 + 2 * i), ACC + i)
+    for i in range(4):
+        e("v_mul_f64 %s, %s, %s", vp(P0 + 2 * i), vp(P0 + 2 * i), vp(GAIN))
+    for i in range(4):
+        e("v_cvt_f32_f64 v%d, %s", G + i, vp(P0 + 2 * i))
+    # ---- ring slot c % 2: its old content (chunk c - 2) leaves first, once the loop has consumed it
+    e("v_add_u32_e32 v%d, s%d, %%[ring%d]", TMP + 2, SPR, ui)
+    e("s_lshr_b32 s%d, s%d, 1", ST0, SPR)                       # 64 records x 4 bytes
+    e("v_add_u32_e32 v%d, s%d, %%[z%d]", TMP + 3, ST0, ui)
+    nofl, go, spin, fail = e.label("nofl"), e.label("go"), e.label("spin"), e.label("fail")
+    e("s_cmp_lt_u32 s%d, 2", SC)
+    e("s_cbranch_scc1 %s", nofl)
+    e("s_sub_u32 s%d, s%d, 1", ST1, SC)                         # consumed >= c - 1
+    e("s_cmp_ge_i32 s%d, s%d", SCONS, ST1)
+    e("s_cbranch_scc1 %s", go)
+    e("s_mov_b32 s%d, 0x%x", SSPIN, SPIN_LIMIT)
+    e.place(spin)
+    e("ds_read_b64 %s, %%[smem] offset:576", vp(FL))
+    e("s_waitcnt lgkmcnt(0)")
+    e("v_readfirstlane_b32 s%d, v%d", SCONS, FL)
+    e("v_readfirstlane_b32 s%d, v%d", ST2, FL + 1)
+    e("s_cmp_ge_i32 s%d, s%d", SCONS, ST1)
+    e("s_cbranch_scc1 %s", go)
+    e("s_cmp_lg_u32 s%d, 0", ST2)                               # the workgroup gave up
+    e("s_cbranch_scc1 %s", fail)
+    e("s_sub_u32 s%d, s%d, 1", SSPIN, SSPIN)
+    e("s_cmp_eq_u32 s%d, 0", SSPIN)
+    e("s_cbranch_scc1 %s", fail)
+    e("s_sleep 2")
+    e("s_branch %s", spin)
+    e.place(fail)
+    e("s_branch Lfail_%=")
+    e.place(go)
+    flush(e, ui)
+    e("s_mov_b32 s%d, 1", SFL)
+    e.place(nofl)
+    # ---- hand-over: the symbols, then the counter (same wave, LDS in order)
+    e("ds_write_b128 v%d, %s", TMP + 2, v4(G))
+    e("s_add_u32 s%d, s%d, 1", ST0, SC)
+    e("v_mov_b32_e32 v%d, s%d", TMP + 1, ST0)
+    e("s_bfe_u32 s%d, s%d, 0x80010", ST0, SIX)                  # 4 x the wave's first unit number
+    e("v_add_u32_e32 v%d, s%d, %%[smem]", TMP + 3, ST0)
+    e("s_mov_b64 exec, 1")
+    e("ds_write_b32 v%d, v%d offset:%d", TMP + 3, TMP + 1, 512 + 4 * ui)
+    e("s_mov_b64 exec, -1")
+
+
+def block(nuw):
+    e = Emit()
+    # ---- parameters (rx_lean_kernel wrote them to LDS): dwords 0-7 source pointers, 8-11 symbol bases, 12 chunks,
+    #      13 decimation offsets (4 bits per unit and frame; bits 16-23: 4 * first unit; bit 31: keep priority 3), 16-17 taps
+    for i in range(5):
+        e("ds_read_b128 %s, %%[prm] offset:%d", v4(PRE + 4 * i), 16 * i)
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(8):
+        e("v_readfirstlane_b32 s%d, v%d", SRC + i, PRE + i)
+    for i in range(4):
+        e("v_readfirstlane_b32 s%d, v%d", SYMB + i, PRE + 8 + i)
+    e("v_readfirstlane_b32 s%d, v%d", SN, PRE + 12)
+    e("v_readfirstlane_b32 s%d, v%d", SIX, PRE + 13)
+    e("v_readfirstlane_b32 s%d, v%d", ST0, PRE + 16)
+    e("v_readfirstlane_b32 s%d, v%d", ST1, PRE + 17)
+    for i in range(4):
+        e("s_load_dwordx16 s[%d:%d], %s, 0x%x", TAP0 + 16 * i, TAP0 + 16 * i + 15, sp(ST0), 64 * i)
+    for reg, bits in CONSTS.items():
+        e("v_mov_b32_e32 v%d, 0x%08x", reg, bits & 0xffffffff)
+        e("v_mov_b32_e32 v%d, 0x%08x", reg + 1, bits >> 32)
+    e("v_mov_b32_e32 v%d, 0x%08x", TMP, ROT45)
+    for r in range(HIST, HIST + 16):
+        e("v_mov_b32_e32 v%d, 0", r)                           # fresh delay lines (qpsk.c:37)
+    e("s_mov_b32 s%d, 0", SC)
+    e("s_mov_b32 s%d, 0", SFL)
+    e("s_waitcnt lgkmcnt(0)")                                  # the taps
+    loads(e, 0)
+    e.place("Lloop_%=")
+    e("s_and_b32 s%d, s%d, 1", ST0, SC)
+    e("s_lshl_b32 s%d, s%d, 9", SPR, ST0)                       # ring slot c % 2: 64 symbols x 8 bytes
+    for ui in range(nuw):
+        unit(e, ui, nuw)
+    e("s_add_u32 s%d, s%d, 1", SC, SC)
+    e("s_cmp_lt_u32 s%d, s%d", SC, SN)
+    e("s_cbranch_scc1 Lloop_%=")
+    e("s_mov_b32 %[status], 0")
+    e("s_branch Lexit_%=")
+    e.place("Lfail_%=")
+    e("s_mov_b32 %[status], 1")
+    e.place("Lexit_%=")
+    e("s_setprio 0")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return e.lines
+
+
+def emit_function(nuw):
+    lines = block(nuw)
+    body = "\n".join('        "%s\\n\\t"' % ln if not ln.endswith(":") else '        "%s\\n"' % ln for ln in lines)
+    ops = ['[prm] "v"(prm_addr)', '[rd] "v"(rd_addr)', '[voff] "v"(voff)', '[symoff] "v"(symoff)', '[smem] "v"(smem_addr)']
+    args = ["unsigned prm_addr", "unsigned rd_addr", "unsigned voff", "unsigned symoff", "unsigned smem_addr"]
+    for ui in range(nuw):
+        for ff in range(2):
+            ops += ['[w0_%d%d] "v"(w.wr0[%d][%d])' % (ui, ff, ui, ff), '[w1_%d%d] "v"(w.wr1[%d][%d])' % (ui, ff, ui, ff)]
+        ops += ['[ring%d] "v"(w.ring[%d])' % (ui, ui), '[z%d] "v"(w.z[%d])' % (ui, ui)]
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"v%d"' % r for r in range(PRE, VLAST + 1)] + ['"s%d"' % r for r in list(range(SRC, 32)) + list(range(35, TAP0 + 64))]
+    nvalu = sum(1 for ln in lines if ln.startswith("v_"))
+    return '''
+/* %(nuw)d unit(s) per wave: %(n)d instructions, %(nvalu)d of them vector ALU */
+__device__ __forceinline__ int fir_lean_loop%(nuw)d(%(args)s, const LeanLaneAddr &w)
+{
+    int status;
+    asm volatile(
+%(body)s
+        : [status] "=s"(status)
+        : %(ops)s
+        : %(clob)s);
+    return status;
+}
+''' % dict(nuw=nuw, n=len([ln for ln in lines if not ln.endswith(":")]), nvalu=nvalu, args=", ".join(args), body=body,
+           ops=",\n          ".join(ops), clob=", ".join(clob))
+
+
+def main():
+    print('''/*
+ * fir_lean_asm.h -- GENERATED by tools/gen_lean_asm.py; do not edit.
+ *
+ * The chunk loop of a FIR wave of rx_lean_kernel (rx_fused.hip): stage, prefetch, filter, gain, flush, hand-over of
+ * one or two two-frame units per 64-symbol chunk, as one instruction stream (see the generator's docstring).
+ *
+ * Contract with the kernel:
+ *   prm_addr   LDS byte address of this wave's 20-dword parameter block: [0..7] source pointers (unit, frame),
+ *              [8..11] symbol store bases per unit (first frame of the unit), [12] chunks per frame (>= 2),
+ *              [13] decimation offsets, 4 bits per (unit, frame), bits 16-23 = 4 x the wave's first unit number, bit 31 =
+ *              stay at priority 3, [16..17] pointer to the 64 distinct taps (the filter is symmetric);
+ *   rd_addr    LDS byte address of the lane's window position 0;   voff = 16 x lane;
+ *   symoff     (lane / 32) x nsym + 2 x (lane %% 32): the lane's two symbols in the unit's symbol rows;
+ *   smem_addr  LDS byte address of the workgroup's Smem (ready[] at +512, consumed at +576, abort flag at +580);
+ *   w          per-lane LDS addresses: window write bases (one 128-sample block below block 0) of the pair's first
+ *              and second sample, ring slot of the lane's two symbols, its two records -- each at chunk parity 0.
+ * Window image, rings and counters are rx_pipe2_kernel's.  Registers v%(v0)d..v%(v1)d and s%(s0)d..s31, s35..s%(s1)d are owned
+ * by the block (s%(t0)d..s%(s1)d hold the taps).  Returns 0, or 1 if the bounded wait for the serial wave ran out.
+ */
+#ifndef QPSK_FIR_LEAN_ASM_H
+#define QPSK_FIR_LEAN_ASM_H
+
+namespace qpsk {
+
+constexpr int FIR_LEAN_FIRST_VGPR = %(v0)d, FIR_LEAN_END_VGPR = %(v1)d + 1;
+
+struct LeanLaneAddr {
+    unsigned wr0[2][2], wr1[2][2];   /* [unit][frame] */
+    unsigned ring[2], z[2];          /* [unit] */
+};
+''' % dict(v0=PRE, v1=VLAST, s0=SRC, s1=TAP0 + 63, t0=TAP0))
+    print(emit_function(1))
+    print(emit_function(2))
+    print("} // namespace qpsk\n#endif")
+
+
+if __name__ == "__main__":
+    main()
