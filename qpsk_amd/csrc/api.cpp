@@ -82,7 +82,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
 #ifdef QPSK_PIPE_PROFILE
 static const int PIPE_VARIANT_MASK = ~0;
 #else
-static const int PIPE_VARIANT_MASK = 4 | 8 | 16 | 64 | 128 | 256 | 512 | 1024;
+static const int PIPE_VARIANT_MASK = 4 | 8 | 16 | 64 | 128 | 256 | 512 | 1024 | 8192;
 #endif
 
 struct qpsk_ctx {
@@ -596,7 +596,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
             layout = ((unsigned long long)(unsigned)tuned(c->tune.layout_lo, 0) << 4) |
                      ((unsigned long long)(unsigned)tuned(c->tune.layout_hi, 0) << 24);
         else if (G >= 2)
-            layout = pipe2_default_layout(G / 2);
+            layout = lean_default_layout(G / 2);
         FusedArgs am = a;
         am.nframes = nframes - nframes % (G > 0 ? G : 1);
         if (wanted && layout && am.nframes > 0 && lean_shape_ok(am, G)) {

@@ -74,6 +74,7 @@ unsigned long long pipe2_default_layout(int NU);        /* 4 bits per hardware w
 int launch_rx_pipe2(const FusedArgs &a, int G, unsigned long long layout, int *status, hipStream_t s);
 /* rx_fused.hip: the same pipeline with the FIR waves' chunk loop as one hand-written stream (fir_lean_asm.h) */
 size_t lean_lds_bytes(int G, int nwin);
+unsigned long long lean_default_layout(int NU);         /* rx_lean_kernel: 1, 5, 5, 5 units on SIMDs 0-3 for a full workgroup */
 bool lean_shape_ok(const FusedArgs &a, int G);          /* one loop per frame, whole chunks, whole even workgroups, ... */
 int launch_rx_lean(const FusedArgs &a, int G, unsigned long long layout, int *status, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,

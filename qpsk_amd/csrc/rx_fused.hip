@@ -46,7 +46,10 @@
 #include "costas_asm.h"
 #include "fir_r2_asm.h"
 #include "fir_r4_asm.h"
-#include "fir_lean_asm.h"
+#include "fir_lean_asm.h"      /* WS_LEAN_SLOTS, the streams */
+#ifdef QPSK_PIPE_PROFILE
+#include "fir_lean_prof_asm.h"
+#endif
 #include "kernels.h"
 
 #ifndef QPSK_PIPE1_ASM
@@ -170,8 +173,8 @@ using namespace pipe;
  * ring (the phase the step started from, four steps per write), then publishes consumed = c + 1.  Shared by rx_fused_pipe_kernel (ring fed by FIR waves) and
  * costas_pipe_kernel (ring fed from already decimated symbols in global memory).
  */
-template <class GM>
-__device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const float2 *dring, float *zring, int G,
+template <class GM, class SM>   /* SM: Smem, or rx_lean_kernel's control block (ready[], consumed, abort_flag) */
+__device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const float2 *dring, float *zring, int G,
                                             int f0, int lane, int nchunks, int *status)
 {
     QPSK_GEOM_CONSTANTS(GM);
@@ -223,7 +226,18 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
     /* full chunks go through the stream that runs across the ring hand-overs (costas_asm.h, costas_asm_run_ring); a
      * first chunk that starts from a loaded phase of -0, a last partial one and the variants below stay chunk by chunk */
 #ifdef QPSK_PIPE_PROFILE
-    const bool ring_stream = fast_clamp && !(a.dbg & (2 | 8 | 16 | 32)) && S == 4 * COSTAS_ASM_GROUP && DR == 2;
+    /* dbg bit 12 (4096): keep the ring stream under dbg 32 and time it (cycles inside the stream / waiting outside it) */
+    const bool ring_prof = (a.dbg & 4096) != 0 && (blockIdx.x == 0 || blockIdx.x == 77);
+    unsigned long long rp_in = 0, rp_out = 0, rp_t = 0, rp_calls = 0;
+    auto rp_tick = [&](unsigned long long &acc) {
+        if (ring_prof) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            if (rp_t) acc += t - rp_t;
+            rp_t = t;
+        }
+    };
+    const bool ring_stream = fast_clamp && !(a.dbg & (2 | 8 | 16 | ((a.dbg & 4096) ? 0 : 32))) && S == 4 * COSTAS_ASM_GROUP && DR == 2;
 #else
     const bool ring_stream = fast_clamp && !(a.dbg & (8 | 16)) && S == 4 * COSTAS_ASM_GROUP && DR == 2;
 #endif
@@ -247,7 +261,14 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
                     unsigned long long fl = 1;
                     if (!__any(__float_as_uint(fr) == 0x80000000u)) {
                         unsigned ks = __builtin_amdgcn_readfirstlane(k);
+#ifdef QPSK_PIPE_PROFILE
+                        rp_tick(rp_out);
+                        rp_calls++;
+#endif
                         costas_asm_run_ring(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kend, al, be, fmin_, fmax_, fl);
+#ifdef QPSK_PIPE_PROFILE
+                        rp_tick(rp_in);
+#endif
                         k = ks;
                     }
                     if (fl != 0 && k < kend) {      /* group k abandoned (or never started): the C++ step, then on */
@@ -348,8 +369,12 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, Smem *sm, const 
 #endif
     }
 #ifdef QPSK_PIPE_PROFILE
-    if (cprof && lane == 0)
+    if (cprof && lane == 0 && !ring_prof)
         printf("serial wave: %d chunks; cycles per chunk: wait for the FIR waves %llu, steps %llu\n", nchunks, cw / nchunks, cs / nchunks);
+    if (ring_prof && lane == 0)
+        printf("wg %3d serial wave: %d chunks, %llu entries into the stream; cycles per chunk inside the stream %llu (= %llu per step), "
+               "outside it (waiting for the FIR waves, redone groups) %llu\n", (int)blockIdx.x, nchunks, rp_calls, rp_in / nchunks,
+               rp_in / nchunks / S, rp_out / nchunks);
 #endif
     st.phase = ph; st.freq = fr;
     if (active && ok) {
@@ -1317,28 +1342,59 @@ int launch_rx_pipe2(const FusedArgs &a0, int G, unsigned long long layout, int *
  * 16-byte aligned frames, whole workgroups of an even number of frames.  Results: the same bits.
  * ======================================================================== */
 namespace lean {
+/*
+ * LDS of rx_lean_kernel (160 KB, filled to the last 200 bytes so that TEN waves can filter: one beside the serial wave
+ * with a single unit, three on each of the other SIMDs with 2 + 2 + 1 -- 1, 5, 5, 5 units on SIMDs 0-3):
+ *   Ctl                      counters (80 bytes; no taps: the stream keeps them in SGPRs)
+ *   windows [nwin][2][WS]    WS = 712 slots per frame: positions 0..633 of the padded image.  A lane reads up to position
+ *                            630; the chunk's last samples (up to 637) matter only as the next chunk's history, which lives
+ *                            in registers -- the stream drops them (fir_lean_asm.h, stage)
+ *   ring rows [rows][ROW]    one row per frame: 128 symbols (1024 bytes), 128 records (512 bytes), 16 bytes of padding: rows
+ *                            1552 bytes = 4 banks (mod 64) apart for the serial wave's 16-byte reads and writes, like the
+ *                            separate rings of the other kernels (1040- and 528-byte rows) at 16 bytes less per frame.
+ *                            rows = max(G, hardware waves): the record half of row w carries hardware wave w's parameter
+ *                            block until the first record is written -- which the serial wave does only once EVERY unit has
+ *                            handed over its first chunk, i.e. after every FIR wave has read its parameters.
+ */
 constexpr int PRM_DWORDS = 20;                        /* per-wave parameter block of the stream */
 constexpr int HW_WAVES = pipe2::MAX_THREADS / 64;
-struct SmemLean {
-    Smem s;                                           /* taps[] unused here: the stream keeps the taps in SGPRs */
-    unsigned prm[HW_WAVES][PRM_DWORDS];
+constexpr int WS = WS_LEAN_SLOTS;
+struct Ctl {
+    int ready[MAX_WAVES];     /* chunks produced, per unit */
+    int consumed;             /* chunks consumed by the serial wave */
+    int abort_flag;
+    int pad_[2];
 };
-static_assert(sizeof(SmemLean) % 16 == 0 && offsetof(Smem, ready) == 512 && offsetof(Smem, consumed) == 576 &&
-              offsetof(Smem, abort_flag) == 580, "fir_lean_asm.h addresses the counters by these offsets");
+struct GeomLean : GeomNarrow {                        /* ring geometry seen by costas_wave / flush_records */
+    static constexpr int DSTRIDE = 194;               /* float2 slots per row: 1552 bytes */
+    static constexpr int ZSTRIDE = 388;               /* floats per row */
+};
+constexpr int ROW_BYTES = 1552, Z_OFFSET_BYTES = 1024;
+static_assert(GeomLean::DSTRIDE * 8 == ROW_BYTES && GeomLean::ZSTRIDE * 4 == ROW_BYTES &&
+              Z_OFFSET_BYTES == DR * GeomNarrow::S * 8 && Z_OFFSET_BYTES + DR * GeomNarrow::S * 4 <= ROW_BYTES &&
+              ROW_BYTES % 16 == 0 && (ROW_BYTES / 4) % 64 == 4, "ring rows: symbols, records, bank spread");
+static_assert(sizeof(Ctl) % 16 == 0 && offsetof(Ctl, ready) == 0 && offsetof(Ctl, consumed) == 64 &&
+              offsetof(Ctl, abort_flag) == 68, "fir_lean_asm.h addresses the counters by these offsets");
+static_assert(PRM_DWORDS * 4 <= ROW_BYTES - Z_OFFSET_BYTES, "a parameter block fits the record half of a row");
 static_assert(FIR_LEAN_END_VGPR <= 168, "three waves per SIMD");
+static_assert(WS % 2 == 0 && pipe2::slot_of(pipe2::PAD * (pipe2::QL - 1) + pipe2::TSTEPS - 1) < WS &&
+              pipe2::slot_of(pipe2::CH + HIST - 1) < WS + 16, "window: every position a lane reads, and a frame's spill stays in the next frame's history slots");
+__device__ __host__ constexpr int rows_of(int G) { return G > HW_WAVES ? G : HW_WAVES; }
 } // namespace lean
 
 template <int NUW>
-__device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::SmemLean *sl, float2 *mywin, float2 *dring,
-                                              float *zring, int hwave, int u0, int f0, int lane, int nchunks, int *status)
+__device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm, unsigned char *rows, float2 *mywin,
+                                              int hwave, int u0, int f0, int lane, int nchunks, int *status)
 {
     using namespace pipe2;
-    using GM = GeomNarrow;
-    Smem *sm = &sl->s;
+    using GM = lean::GeomLean;
+    constexpr int WS = lean::WS;
+    float2 *dring = reinterpret_cast<float2 *>(rows);
+    float *zring = reinterpret_cast<float *>(rows + lean::Z_OFFSET_BYTES);
     const int L = a.frame_size, N = a.nsym;
     const int fl = lane / QL, q = lane % QL;
     const bool simd0 = (hwave & 3) == 0;                 /* placed beside the serial wave (layout): keeps priority 3 */
-    unsigned *prm = sl->prm[hwave];
+    unsigned *prm = reinterpret_cast<unsigned *>(rows + (size_t)hwave * lean::ROW_BYTES + lean::Z_OFFSET_BYTES);
     unsigned ixpack = ((unsigned)(4 * u0) << 16) | (simd0 && !(a.dbg & 1024) ? 0x80000000u : 0u);
     LeanLaneAddr w;
 #pragma unroll
@@ -1367,6 +1423,8 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::SmemLean
             prm[8 + 2 * ui + 1] = (unsigned)(sb >> 32);
         }
     }
+    w.wlim = lds_addr(mywin + WS + (WS - 2));            /* the second frame's last pair */
+    w.wpad = lds_addr(mywin + WS + PAD);                 /* its first pad pair (slots 16, 17): never read */
     if (lane == 0) {
         prm[12] = (unsigned)nchunks;
         prm[13] = ixpack;
@@ -1376,6 +1434,22 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::SmemLean
     if (simd0 && !(a.dbg & 1024)) __builtin_amdgcn_s_setprio(3);
     const unsigned rd = lds_addr(mywin + fl * WS + (PAD + PADS) * q);
     int st;
+#ifdef QPSK_PIPE_PROFILE
+    if (a.dbg & 32) {      /* measurement build: the stream with cycle stamps between the phases of a unit */
+        unsigned pf[FIR_LEAN_NPROF];
+        unsigned long long t0, t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        if constexpr (NUW == 2)
+            st = fir_lean_loop2_prof(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w, pf);
+        else
+            st = fir_lean_loop1_prof(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w, pf);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        if ((blockIdx.x == 0 || blockIdx.x == 77) && lane == 0)
+            printf("wg %3d FIR wave hw %2d (%d units): %d chunks, %llu cycles in the stream; per chunk: samples %u, stage+loads %u, "
+                   "filter+gain %u, wait for the loop %u, flush %u, hand-over %u\n", (int)blockIdx.x, hwave, NUW, nchunks, t1 - t0,
+                   pf[0] / nchunks, pf[1] / nchunks, pf[2] / nchunks, pf[3] / nchunks, pf[4] / nchunks, pf[5] / nchunks);
+    } else
+#endif
     if constexpr (NUW == 2)
         st = fir_lean_loop2(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w);
     else
@@ -1400,14 +1474,12 @@ __global__ void __launch_bounds__(pipe2::MAX_THREADS)
 rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
 {
     using namespace pipe2;
-    using GM = GeomNarrow;
+    using GM = lean::GeomLean;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    lean::SmemLean *sl = reinterpret_cast<lean::SmemLean *>(smem_raw);
-    Smem *sm = &sl->s;
+    lean::Ctl *sm = reinterpret_cast<lean::Ctl *>(smem_raw);
     const int G = a.G;
-    float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(lean::SmemLean));   /* [nwin][UF][WS] */
-    float2 *dring = win + (size_t)nwin * UF * WS;                                    /* [G][DSTRIDE] */
-    float *zring = reinterpret_cast<float *>(dring + (size_t)G * GM::DSTRIDE);       /* [G][ZSTRIDE] */
+    float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(lean::Ctl));          /* [nwin][UF][WS] */
+    unsigned char *rows = reinterpret_cast<unsigned char *>(win + (size_t)nwin * UF * lean::WS);   /* [rows_of(G)][ROW_BYTES] */
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f0 = blockIdx.x * G;
@@ -1417,8 +1489,9 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
     if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
     __syncthreads();
 
-    if (wave == 0) {
-        costas_wave<GM>(a, sm, dring, zring, G, f0, lane, nchunks, status);   /* a.mixed == 2: lane g waits on ready[g / 2] */
+    if (wave == 0) {   /* a.mixed == 2: lane g waits on ready[g / 2] */
+        costas_wave<GM>(a, sm, reinterpret_cast<const float2 *>(rows), reinterpret_cast<float *>(rows + lean::Z_OFFSET_BYTES), G,
+                        f0, lane, nchunks, status);
         return;
     }
     const int mine = (int)((layout >> (4 * wave)) & 15);
@@ -1429,19 +1502,33 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
         u0 += cv;
         widx += cv != 0;
     }
-    float2 *mywin = win + (size_t)widx * UF * WS;
+    float2 *mywin = win + (size_t)widx * UF * lean::WS;
     if (mine == 2)
-        fir_wave_lean<2>(a, sl, mywin, dring, zring, wave, u0, f0, lane, nchunks, status);
+        fir_wave_lean<2>(a, sm, rows, mywin, wave, u0, f0, lane, nchunks, status);
     else
-        fir_wave_lean<1>(a, sl, mywin, dring, zring, wave, u0, f0, lane, nchunks, status);
+        fir_wave_lean<1>(a, sm, rows, mywin, wave, u0, f0, lane, nchunks, status);
 }
 
 size_t lean_lds_bytes(int G, int nwin)
 {
-    using GM = GeomNarrow;
-    size_t b = sizeof(lean::SmemLean) + sizeof(float2) * ((size_t)nwin * pipe2::UF * pipe2::WS + (size_t)G * GM::DSTRIDE) +
-               sizeof(float) * (size_t)G * GM::ZSTRIDE;
+    size_t b = sizeof(lean::Ctl) + sizeof(float2) * (size_t)nwin * pipe2::UF * lean::WS + (size_t)lean::rows_of(G) * lean::ROW_BYTES;
     return (b + 15) & ~(size_t)15;
+}
+
+/*
+ * rx_lean_kernel's layout for NU units (4 bits per hardware wave, as rx_pipe2_kernel's).  A full workgroup (16 units): ONE
+ * unit beside the serial wave (hardware wave 4) and 2 + 2 + 1 on the three waves of each other SIMD -- 1, 5, 5, 5.  [Measured,
+ * every vector instruction of a wave on SIMD 0 costs the serial wave its 4 cycles, whatever the priorities;
+ * with two units there the serial wave takes 239 cycles per step instead of 162 and is the slowest of the workgroup, with
+ * one 191, and three SIMDs with five units each take as long.]  Fewer units: rx_pipe2_kernel's layouts.
+ */
+unsigned long long lean_default_layout(int NU)
+{
+    if (NU != pipe2::MAX_UNITS) return pipe2_default_layout(NU);
+    static const int cnt[12] = {0, 2, 2, 2, 1, 2, 2, 2, 0, 1, 1, 1};
+    unsigned long long layout = 0;
+    for (int w = 1; w < 12; w++) layout |= (unsigned long long)cnt[w] << (4 * w);
+    return layout;
 }
 
 /* what rx_lean_kernel serves (see its header); the caller has checked CYCLES = 8, the alignment and the filter's symmetry */

@@ -3,6 +3,7 @@
 one gfx950 instruction stream per wave shape (1 or 2 two-frame units per wave).
 
     python tools/gen_lean_asm.py > qpsk_amd/csrc/fir_lean_asm.h
+    python tools/gen_lean_asm.py --profile > qpsk_amd/csrc/fir_lean_prof_asm.h      (measurement build only)
 
 What one iteration of the loop does for one unit (2 frames x 64 symbols of chunk c; reference rrc_fir.c:17-30 evaluated at
 the samples qpsk.c:190 keeps, then the slicer of qpsk.c:74-79 on the loop's de-rotated symbols, qpsk.c:197):
@@ -53,6 +54,26 @@ SRC = 10            # s10..s17   source pointers unit ui, frame ff -> SRC + 4 ui
 SYMB = 18           # s18..s21   symbol store bases per unit
 SC, SN, SPR, SSPIN, ST0, ST1, ST2, ST3, SIX, SFL, SCONS = 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 35
 SPIN_LIMIT = 1 << 24
+CTL_READY, CTL_CONSUMED = 0, 64        # lean::Ctl (rx_fused.hip): ready[16], consumed, abort flag
+WS_SLOTS = 712                         # slots per frame window (rx_fused.hip, lean::WS): positions 0..633; a lane never reads past 630
+# measurement variant (--profile -> fir_lean_prof_asm.h, only compiled into the -DQPSK_PIPE_PROFILE library): shader cycles per
+# phase of a unit, accumulated in v160..v165 (v166 scratch, v167 the last stamp) and handed back through six outputs
+PROFILE = False
+NPROF = 6            # wait for the samples | stage + issue loads | filter + gain | wait for the loop | flush | hand-over + priority
+PACC, PTMP, PLAST = 160, 166, 167
+
+
+def stamp(e, k):
+    """close phase k: cycles since the last stamp -> accumulator k (the SMEM read shares lgkmcnt with LDS: the wait also drains
+    the wave's LDS operations, which the next phase would have waited for in order anyway)"""
+    if not PROFILE:
+        return
+    e("s_memtime %s", sp(ST2))
+    e("s_waitcnt lgkmcnt(0)")
+    if k >= 0:
+        e("v_sub_u32_e32 v%d, s%d, v%d", PTMP, ST2, PLAST)
+        e("v_add_u32_e32 v%d, v%d, v%d", PACC + k, PTMP, PACC + k)
+    e("v_mov_b32_e32 v%d, s%d", PLAST, ST2)
 
 CONSTS = {   # name -> (register, double as hex bits)
     K2PI: 0x3FE45F306DC9C883, HPI: 0x3FF921FB54442D18, C4: 0x3EF99343027BF8C3, S3: 0xBF2994EB3774CF24,
@@ -103,9 +124,13 @@ def tap_operand(k):
     return sp(r - 1), "op_sel:[1,0]"
 
 
-def wreg(t):
+def wreg_base(t):
     b, u = divmod(t, C)
-    return vp(W0 + 16 * (b % NW) + 2 * u)
+    return W0 + 16 * (b % NW) + 2 * u
+
+
+def wreg(t):
+    return vp(wreg_base(t))
 
 
 def fetch(e, b):
@@ -119,14 +144,17 @@ def fetch(e, b):
     return n
 
 
-def filter_stream(e):
-    """the sum of fir_r2_asm.h (tools/gen_fir_asm.py) with the taps as SGPR operands"""
+def filter_stream(e, packed=True):
+    """the sum of fir_r2_asm.h (tools/gen_fir_asm.py) with the taps as SGPR operands.  packed=False (not emitted; kept for
+    the record): the same products and sums as single-float instructions, re and im apart -- tried for the FIR wave beside
+    the serial wave on the idea that a single-float instruction holds the SIMD for 2 cycles; it holds it for 4 like a packed
+    one, so twice the instructions cost the serial wave twice the cycles: 0.316 against 0.275 ms at 8192 frames."""
     reads = {}
     for d in range(min(DEPTH, NB)):
         reads[d] = fetch(e, d)
     e("v_mov_b64 %s, 0", vp(ACC))
     e("v_mov_b64 %s, 0", vp(ACC + 2))
-    acc = [vp(ACC), vp(ACC + 2)]
+    acc = [ACC, ACC + 2]
     nmul = 0
     for b in range(NB):
         if b + DEPTH < NB:
@@ -142,10 +170,17 @@ def filter_stream(e):
                 for sym in range(R):
                     k = t - STEP * sym
                     if 0 <= k < NTAPS:
-                        treg, sel = tap_operand(k)
-                        p = vp(P0 + 2 * np_)
-                        muls.append("v_pk_mul_f32 %s, %s, %s %s" % (p, treg, wreg(t), sel))
-                        adds.append("v_pk_add_f32 %s, %s, %s" % (acc[sym], acc[sym], p))
+                        p = P0 + 2 * np_
+                        if packed:
+                            treg, sel = tap_operand(k)
+                            muls.append("v_pk_mul_f32 %s, %s, %s %s" % (vp(p), treg, wreg(t), sel))
+                            adds.append("v_pk_add_f32 %s, %s, %s" % (vp(acc[sym]), vp(acc[sym]), vp(p)))
+                        else:
+                            ts = "s%d" % (TAP0 + (k if k <= 63 else 126 - k))
+                            w = wreg_base(t)
+                            for h in range(2):      # re*tap, im*tap (rrc_fir.c:24-25), then the two sums
+                                muls.append("v_mul_f32_e32 v%d, %s, v%d" % (p + h, ts, w + h))
+                                adds.append("v_add_f32_e32 v%d, v%d, v%d" % (acc[sym] + h, acc[sym] + h, p + h))
                         np_ += 1
                         nmul += 1
             for x in muls + adds:
@@ -169,8 +204,19 @@ def stage_frame(e, ui, ff):
     e("s_mov_b64 exec, %s", sp(ST2))
     e("ds_write_b128 %s, %s", wr0, v4(hist))
     e("s_mov_b64 exec, -1")
+    # The window keeps positions 0..633 (WS_SLOTS slots; no lane reads past 630): the last samples of a chunk, which matter only
+    # as the NEXT chunk's history (registers), would land past it.  Frame 0's spill into the first slots of frame 1 -- staged
+    # after it, in order -- is harmless; frame 1's would hit the next wave's window, so those lanes write a pad slot instead.
+    def clamped(dst, base):
+        e("v_add_u32_e32 v%d, 0x%x, %s", dst, 4 * BLK_BYTES, base)
+        e("v_cmp_gt_u32_e32 vcc, v%d, %%[wlim]", dst)
+        e("v_cndmask_b32_e32 v%d, v%d, %%[wpad], vcc", dst, dst)
     for j in range(4):
-        e("ds_write_b128 %s, %s offset:%d", wr0, v4(PRE + 16 * ff + 4 * j), (j + 1) * BLK_BYTES)
+        if ff == 1 and j == 3:
+            clamped(P0, wr0)
+            e("ds_write_b128 v%d, %s", P0, v4(PRE + 16 * ff + 4 * j))
+        else:
+            e("ds_write_b128 %s, %s offset:%d", wr0, v4(PRE + 16 * ff + 4 * j), (j + 1) * BLK_BYTES)
     e("s_branch %s", done)
     e.place(odd)
     e("s_mov_b64 exec, %s", sp(ST2))
@@ -181,8 +227,14 @@ def stage_frame(e, ui, ff):
     e("s_mov_b64 exec, -1")
     for j in range(4):
         r = PRE + 16 * ff + 4 * j
-        e("ds_write_b64 %s, %s offset:%d", wr0, vp(r), (j + 1) * BLK_BYTES)
-        e("ds_write_b64 %s, %s offset:%d", wr1, vp(r + 2), (j + 1) * BLK_BYTES)
+        if ff == 1 and j == 3:
+            clamped(P0, wr0)
+            clamped(P0 + 1, wr1)
+            e("ds_write_b64 v%d, %s", P0, vp(r))
+            e("ds_write_b64 v%d, %s", P0 + 1, vp(r + 2))
+        else:
+            e("ds_write_b64 %s, %s offset:%d", wr0, vp(r), (j + 1) * BLK_BYTES)
+            e("ds_write_b64 %s, %s offset:%d", wr1, vp(r + 2), (j + 1) * BLK_BYTES)
     e.place(done)
     r = PRE + 16 * ff + 12
     e("v_mov_b64 %s, %s", vp(hist), vp(r))
@@ -277,12 +329,12 @@ def flush(e, ui):
     e("s_addc_u32 s%d, s%d, 0", SYMB + 2 * ui + 1, SYMB + 2 * ui + 1)
 
 
-def unit(e, ui, nuw):
+def unit(e, ui, nuw, packed=True):
     last = ui == nuw - 1
     nx = (ui + 1) % nuw
     # ---- priority by need: the fewer chunks this wave is ahead of the loop, the higher (rx_fused.hip, rx_pipe2_kernel)
     pr_done, pr1, pr2 = e.label("pr"), e.label("pr"), e.label("pr")
-    e("ds_read_b32 v%d, %%[smem] offset:576", TMP + 1)
+    e("ds_read_b32 v%d, %%[smem] offset:%d", TMP + 1, CTL_CONSUMED)
     e("s_waitcnt lgkmcnt(0)")
     e("v_readfirstlane_b32 s%d, v%d", SCONS, TMP + 1)
     e("s_bitcmp1_b32 s%d, 31", SIX)                             # the FIR wave beside the serial wave keeps priority 3
@@ -300,6 +352,7 @@ def unit(e, ui, nuw):
     e.place(pr2)
     e("s_setprio 0")
     e.place(pr_done)
+    stamp(e, 5)
     # ---- the unit's samples: everything issued after their loads is the previous iteration's symbol store, if any
     w1, w2 = e.label("vm"), e.label("vm")
     e("s_cmp_eq_u32 s%d, 0", SFL)
@@ -309,6 +362,7 @@ def unit(e, ui, nuw):
     e.place(w1)
     e("s_waitcnt vmcnt(0)")
     e.place(w2)
+    stamp(e, 0)
     e("s_mov_b32 s%d, 0", SFL)
     stage_frame(e, ui, 0)
     stage_frame(e, ui, 1)
@@ -322,14 +376,16 @@ def unit(e, ui, nuw):
         e.place(skip)
     else:
         loads(e, nx)
+    stamp(e, 1)
     # ---- filter, gain
-    filter_stream(e)
+    filter_stream(e, packed)
     for i in range(4):
         e("v_cvt_f64_f32 %s, v%d", vp(P0 + 2 * i), ACC + i)
     for i in range(4):
         e("v_mul_f64 %s, %s, %s", vp(P0 + 2 * i), vp(P0 + 2 * i), vp(GAIN))
     for i in range(4):
         e("v_cvt_f32_f64 v%d, %s", G + i, vp(P0 + 2 * i))
+    stamp(e, 2)
     # ---- ring slot c % 2: its old content (chunk c - 2) leaves first, once the loop has consumed it
     e("v_add_u32_e32 v%d, s%d, %%[ring%d]", TMP + 2, SPR, ui)
     e("s_lshr_b32 s%d, s%d, 1", ST0, SPR)                       # 64 records x 4 bytes
@@ -342,7 +398,7 @@ def unit(e, ui, nuw):
     e("s_cbranch_scc1 %s", go)
     e("s_mov_b32 s%d, 0x%x", SSPIN, SPIN_LIMIT)
     e.place(spin)
-    e("ds_read_b64 %s, %%[smem] offset:576", vp(FL))
+    e("ds_read_b64 %s, %%[smem] offset:%d", vp(FL), CTL_CONSUMED)
     e("s_waitcnt lgkmcnt(0)")
     e("v_readfirstlane_b32 s%d, v%d", SCONS, FL)
     e("v_readfirstlane_b32 s%d, v%d", ST2, FL + 1)
@@ -358,9 +414,12 @@ def unit(e, ui, nuw):
     e.place(fail)
     e("s_branch Lfail_%=")
     e.place(go)
+    stamp(e, 3)
     flush(e, ui)
     e("s_mov_b32 s%d, 1", SFL)
+    stamp(e, 4)
     e.place(nofl)
+    stamp(e, -1)
     # ---- hand-over: the symbols, then the counter (same wave, LDS in order)
     e("ds_write_b128 v%d, %s", TMP + 2, v4(G))
     e("s_add_u32 s%d, s%d, 1", ST0, SC)
@@ -368,11 +427,11 @@ def unit(e, ui, nuw):
     e("s_bfe_u32 s%d, s%d, 0x80010", ST0, SIX)                  # 4 x the wave's first unit number
     e("v_add_u32_e32 v%d, s%d, %%[smem]", TMP + 3, ST0)
     e("s_mov_b64 exec, 1")
-    e("ds_write_b32 v%d, v%d offset:%d", TMP + 3, TMP + 1, 512 + 4 * ui)
+    e("ds_write_b32 v%d, v%d offset:%d", TMP + 3, TMP + 1, CTL_READY + 4 * ui)
     e("s_mov_b64 exec, -1")
 
 
-def block(nuw):
+def block(nuw, packed=True):
     e = Emit()
     # ---- parameters (rx_lean_kernel wrote them to LDS): dwords 0-7 source pointers, 8-11 symbol bases, 12 chunks,
     #      13 decimation offsets (4 bits per unit and frame; bits 16-23: 4 * first unit; bit 31: keep priority 3), 16-17 taps
@@ -399,11 +458,15 @@ def block(nuw):
     e("s_mov_b32 s%d, 0", SFL)
     e("s_waitcnt lgkmcnt(0)")                                  # the taps
     loads(e, 0)
+    if PROFILE:
+        for k in range(NPROF):
+            e("v_mov_b32_e32 v%d, 0", PACC + k)
+        stamp(e, -1)
     e.place("Lloop_%=")
     e("s_and_b32 s%d, s%d, 1", ST0, SC)
     e("s_lshl_b32 s%d, s%d, 9", SPR, ST0)                       # ring slot c % 2: 64 symbols x 8 bytes
     for ui in range(nuw):
-        unit(e, ui, nuw)
+        unit(e, ui, nuw, packed)
     e("s_add_u32 s%d, s%d, 1", SC, SC)
     e("s_cmp_lt_u32 s%d, s%d", SC, SN)
     e("s_cbranch_scc1 Lloop_%=")
@@ -414,37 +477,68 @@ def block(nuw):
     e.place("Lexit_%=")
     e("s_setprio 0")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if PROFILE:
+        for k in range(NPROF):
+            e("v_mov_b32_e32 %%[pf%d], v%d", k, PACC + k)
     return e.lines
 
 
-def emit_function(nuw):
-    lines = block(nuw)
+def emit_function(nuw, packed=True):
+    lines = block(nuw, packed)
     body = "\n".join('        "%s\\n\\t"' % ln if not ln.endswith(":") else '        "%s\\n"' % ln for ln in lines)
-    ops = ['[prm] "v"(prm_addr)', '[rd] "v"(rd_addr)', '[voff] "v"(voff)', '[symoff] "v"(symoff)', '[smem] "v"(smem_addr)']
+    ops = ['[prm] "v"(prm_addr)', '[rd] "v"(rd_addr)', '[voff] "v"(voff)', '[symoff] "v"(symoff)', '[smem] "v"(smem_addr)',
+           '[wlim] "v"(w.wlim)', '[wpad] "v"(w.wpad)']
     args = ["unsigned prm_addr", "unsigned rd_addr", "unsigned voff", "unsigned symoff", "unsigned smem_addr"]
     for ui in range(nuw):
         for ff in range(2):
             ops += ['[w0_%d%d] "v"(w.wr0[%d][%d])' % (ui, ff, ui, ff), '[w1_%d%d] "v"(w.wr1[%d][%d])' % (ui, ff, ui, ff)]
         ops += ['[ring%d] "v"(w.ring[%d])' % (ui, ui), '[z%d] "v"(w.z[%d])' % (ui, ui)]
-    clob = ['"memory"', '"vcc"', '"scc"'] + ['"v%d"' % r for r in range(PRE, VLAST + 1)] + ['"s%d"' % r for r in list(range(SRC, 32)) + list(range(35, TAP0 + 64))]
+    vlast = PLAST if PROFILE else VLAST
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"v%d"' % r for r in range(PRE, vlast + 1)] + ['"s%d"' % r for r in list(range(SRC, 32)) + list(range(35, TAP0 + 64))]
     nvalu = sum(1 for ln in lines if ln.startswith("v_"))
+    outs = ['[status] "=s"(status)'] + (['[pf%d] "=&v"(prof[%d])' % (k, k) for k in range(NPROF)] if PROFILE else [])
     return '''
-/* %(nuw)d unit(s) per wave: %(n)d instructions, %(nvalu)d of them vector ALU */
-__device__ __forceinline__ int fir_lean_loop%(nuw)d(%(args)s, const LeanLaneAddr &w)
+/* %(nuw)d unit(s) per wave%(how)s: %(n)d instructions, %(nvalu)d of them vector ALU */
+__device__ __forceinline__ int fir_lean_loop%(nuw)d%(sfx)s(%(args)s, const LeanLaneAddr &w%(parg)s)
 {
     int status;
     asm volatile(
 %(body)s
-        : [status] "=s"(status)
+        : %(outs)s
         : %(ops)s
         : %(clob)s);
     return status;
 }
 ''' % dict(nuw=nuw, n=len([ln for ln in lines if not ln.endswith(":")]), nvalu=nvalu, args=", ".join(args), body=body,
-           ops=",\n          ".join(ops), clob=", ".join(clob))
+           ops=",\n          ".join(ops), clob=", ".join(clob), outs=",\n          ".join(outs),
+           sfx=("" if packed else "u") + ("_prof" if PROFILE else ""),
+           how="" if packed else ", the filter in single-float instructions (the wave beside the serial wave)", parg=", unsigned (&prof)[%d]" % NPROF if PROFILE else "")
+
+
+def main_profile():
+    print('''/*
+ * fir_lean_prof_asm.h -- GENERATED by tools/gen_lean_asm.py --profile; do not edit.  MEASUREMENT BUILD ONLY
+ * (-DQPSK_PIPE_PROFILE): fir_lean_asm.h's streams with s_memtime stamps between the phases of a unit; prof[] returns the
+ * shader cycles the wave spent 0: waiting for its prefetched samples, 1: staging the window and issuing the next loads,
+ * 2: filter + gain, 3: waiting for the serial wave (consumed), 4: flush, 5: hand-over, priority, loop overhead.
+ */
+#ifndef QPSK_FIR_LEAN_PROF_ASM_H
+#define QPSK_FIR_LEAN_PROF_ASM_H
+#include "fir_lean_asm.h"
+
+namespace qpsk {
+constexpr int FIR_LEAN_NPROF = %d;
+''' % NPROF)
+    print(emit_function(1))
+    print(emit_function(2))
+    print("} // namespace qpsk\n#endif")
 
 
 def main():
+    global PROFILE
+    if "--profile" in sys.argv:
+        PROFILE = True
+        return main_profile()
     print('''/*
  * fir_lean_asm.h -- GENERATED by tools/gen_lean_asm.py; do not edit.
  *
@@ -458,9 +552,10 @@ def main():
  *              stay at priority 3, [16..17] pointer to the 64 distinct taps (the filter is symmetric);
  *   rd_addr    LDS byte address of the lane's window position 0;   voff = 16 x lane;
  *   symoff     (lane / 32) x nsym + 2 x (lane %% 32): the lane's two symbols in the unit's symbol rows;
- *   smem_addr  LDS byte address of the workgroup's Smem (ready[] at +512, consumed at +576, abort flag at +580);
+ *   smem_addr  LDS byte address of the workgroup's control block (lean::Ctl: ready[] at +0, consumed at +64, abort flag at +68);
  *   w          per-lane LDS addresses: window write bases (one 128-sample block below block 0) of the pair's first
- *              and second sample, ring slot of the lane's two symbols, its two records -- each at chunk parity 0.
+ *              and second sample, ring slot of the lane's two symbols, its two records -- each at chunk parity 0; wlim, wpad:
+ *              see the struct.
  * Window image, rings and counters are rx_pipe2_kernel's.  Registers v%(v0)d..v%(v1)d and s%(s0)d..s31, s35..s%(s1)d are owned
  * by the block (s%(t0)d..s%(s1)d hold the taps).  Returns 0, or 1 if the bounded wait for the serial wave ran out.
  */
@@ -470,12 +565,15 @@ def main():
 namespace qpsk {
 
 constexpr int FIR_LEAN_FIRST_VGPR = %(v0)d, FIR_LEAN_END_VGPR = %(v1)d + 1;
+constexpr int WS_LEAN_SLOTS = %(ws)d;   /* slots per frame window: the stage drops what would land past the second frame's */
 
 struct LeanLaneAddr {
     unsigned wr0[2][2], wr1[2][2];   /* [unit][frame] */
     unsigned ring[2], z[2];          /* [unit] */
+    unsigned wlim, wpad;             /* wave-uniform: byte address of the last 16-byte pair of the wave's second frame window, and of
+                                        a pad pair in it (where a lane writes samples that would land past the window) */
 };
-''' % dict(v0=PRE, v1=VLAST, s0=SRC, s1=TAP0 + 63, t0=TAP0))
+''' % dict(v0=PRE, v1=VLAST, s0=SRC, s1=TAP0 + 63, t0=TAP0, ws=WS_SLOTS))
     print(emit_function(1))
     print(emit_function(2))
     print("} // namespace qpsk\n#endif")
