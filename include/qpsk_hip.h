@@ -147,6 +147,14 @@ int qpsk_ctx_set_loop(qpsk_ctx *ctx, float alpha, float beta, float min_freq, fl
 int qpsk_rx_batch(qpsk_ctx *ctx, const float *d_in, int nframes, uint8_t *d_sym, float *d_freq,
                   float *d_phase, float *d_costas, int32_t *d_index, float *d_hz);
 
+/* The same with the frames frame_pitch complex samples apart in d_in (frame_pitch >= frame_size, even; the samples between
+ * two frames are never read).  Why a caller would: with frames a power of two apart (16384 samples = 128 KB) every frame's
+ * sample n sits in the same HBM channel group, and a batch kernel streams sample n of ALL its frames at about the same time --
+ * measured on MI355X, the memory side then delivers 4.4 TB/s to this access pattern against 5.2 TB/s at a pitch of
+ * frame_size + 512 samples.  QPSK_TIMING_FIXED only for a pitch other than frame_size. */
+int qpsk_rx_batch_pitched(qpsk_ctx *ctx, const float *d_in, long long frame_pitch, int nframes, uint8_t *d_sym,
+                          float *d_freq, float *d_phase, float *d_costas, int32_t *d_index, float *d_hz);
+
 /* The same with nbw Costas loops per frame sharing one FIR pass (loop
  * bandwidth sweep, README.md:12).  Outputs are [nframes][nbw][...]. */
 int qpsk_rx_batch_bw(qpsk_ctx *ctx, const float *d_in, int nframes, const float *h_loop_bw, int nbw,

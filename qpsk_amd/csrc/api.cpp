@@ -152,6 +152,9 @@ static int check_status(qpsk_ctx *c)
     if (st == STATUS_PHASE_RANGE)
         return fail(QPSK_ERR_RANGE, "Costas loop phase beyond the bounded 2 pi wrap (input amplitude far outside the modem's range; "
                                     "the reference's phase_wrap() would spin or hang, costas_loop.c:61-67); results of the calls since the last synchronisation are invalid");
+    if (st == STATUS_NONFINITE)
+        return fail(QPSK_ERR_RANGE, "a Costas loop ended on a NaN / Inf state: the input held a non-finite sample (the reference hangs in phase_wrap() "
+                                    "on an infinite phase, costas_loop.c:61-67); results of the calls since the last synchronisation are invalid");
     if (st != 0) return fail(QPSK_ERR_HIP, "kernel status %d", st);
     return QPSK_OK;
 }
@@ -485,11 +488,16 @@ static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int
     return QPSK_OK;
 }
 
-static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw, uint8_t *d_sym, float *d_freq,
-                           float *d_phase, float *d_costas, int32_t *d_index, float *d_hz)
+static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch, int nframes, int nbw, uint8_t *d_sym,
+                           float *d_freq, float *d_phase, float *d_costas, int32_t *d_index, float *d_hz)
 {
     if (!c || !d_in || !d_sym) return fail(QPSK_ERR_ARG, "qpsk_rx_batch: null context, input or symbol buffer");
     if (nframes <= 0) return fail(QPSK_ERR_ARG, "qpsk_rx_batch: nframes = %d", nframes);
+    if (frame_pitch == 0) frame_pitch = c->prm.frame_size;
+    if (frame_pitch < c->prm.frame_size)
+        return fail(QPSK_ERR_ARG, "qpsk_rx_batch_pitched: frame_pitch %lld below frame_size %d", frame_pitch, c->prm.frame_size);
+    if (frame_pitch != c->prm.frame_size && c->prm.timing_mode != QPSK_TIMING_FIXED)
+        return fail(QPSK_ERR_ARG, "qpsk_rx_batch_pitched: a pitch other than frame_size needs QPSK_TIMING_FIXED (the timing estimators read packed frames)");
     if (bind(c)) return QPSK_ERR_HIP;
     const int32_t *idx = nullptr;
     int rc = timing_indices(c, d_in, nframes, &idx);
@@ -497,6 +505,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
 
     FusedArgs a{};
     a.x = reinterpret_cast<const float2 *>(d_in);
+    a.frame_pitch = (size_t)frame_pitch;
     a.nframes = nframes;
     a.frame_size = c->prm.frame_size;
     a.cycles = c->cycles;
@@ -519,7 +528,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
     a.status = c->d_status;
     /* the pipeline kernel (rx_fused.hip) is built for CYCLES = 8, 16-byte aligned frames and an index
      * below CYCLES; everything else takes the generic chunked kernel (kernels.hip) */
-    const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 &&
+    const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 && (frame_pitch % 2) == 0 &&
                          ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames(1) <= 64 &&
                          tuned(c->tune.generic, 0) == 0;
     /* Two pipeline kernels [measured, DESIGN.md 4.1]: up to 16 frames per CU the recurrence is the limit and the
@@ -611,7 +620,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, int nframes, int nbw,
                     FusedArgs ar = a;
                     const size_t o = (size_t)am.nframes;
                     ar.nframes = rem;
-                    ar.x += o * (size_t)a.frame_size;
+                    ar.x += o * a.frame_pitch;
                     if (ar.index) ar.index += o;
                     ar.sym += o * (size_t)a.nsym;
                     if (ar.freq) ar.freq += o;
@@ -645,7 +654,18 @@ int qpsk_rx_batch(qpsk_ctx *c, const float *d_in, int nframes, uint8_t *d_sym, f
         if (bind(c)) return QPSK_ERR_HIP;
         if (int rg = use_context_gains(c)) return rg;
     }
-    return rx_batch_common(c, d_in, nframes, 1, d_sym, d_freq, d_phase, d_costas, d_index, d_hz);
+    return rx_batch_common(c, d_in, 0, nframes, 1, d_sym, d_freq, d_phase, d_costas, d_index, d_hz);
+}
+
+int qpsk_rx_batch_pitched(qpsk_ctx *c, const float *d_in, long long frame_pitch, int nframes, uint8_t *d_sym, float *d_freq,
+                          float *d_phase, float *d_costas, int32_t *d_index, float *d_hz)
+{
+    if (c) {
+        if (bind(c)) return QPSK_ERR_HIP;
+        if (int rg = use_context_gains(c)) return rg;
+    }
+    if (frame_pitch <= 0) return fail(QPSK_ERR_ARG, "qpsk_rx_batch_pitched: frame_pitch = %lld", frame_pitch);
+    return rx_batch_common(c, d_in, frame_pitch, nframes, 1, d_sym, d_freq, d_phase, d_costas, d_index, d_hz);
 }
 
 int qpsk_rx_batch_bw(qpsk_ctx *c, const float *d_in, int nframes, const float *h_loop_bw, int nbw, uint8_t *d_sym,
@@ -662,7 +682,7 @@ int qpsk_rx_batch_bw(qpsk_ctx *c, const float *d_in, int nframes, const float *h
         c->h_gains = g;
         HIP_TRY(hipMemcpyAsync(c->d_gains, c->h_gains.data(), sizeof(float) * g.size(), hipMemcpyHostToDevice, c->stream));
     }
-    return rx_batch_common(c, d_in, nframes, nbw, d_sym, d_freq, d_phase, nullptr, d_index, nullptr);
+    return rx_batch_common(c, d_in, 0, nframes, nbw, d_sym, d_freq, d_phase, nullptr, d_index, nullptr);
 }
 
 /* Costas + slicer over decimated symbols already in device memory (qpsk.c:196-212): the pipeline kernel with

@@ -49,8 +49,8 @@
  *   100:101 x / d*C      102:103 beta*d, alpha*d   104:105 n / x3 / d*S     106:107 xr / d
  *   108:109 x2 / s       110:111 cos chain (v110 = C)   112:113 sin chain (v112 = S)
  *   114:115 T            116:117 the magic sum of the range reduction
- *   118 f2   119 p+f2    120:123, 136:139 two pairs of decimated symbols   126 running min
- *   127 2pi hi   128:129 +-2pi   130,131 group-start phase/freq    133, 135 frequency ping-pong
+ *   118 freq (clamped in place by the next step's head)    120:123, 136:139 two pairs of decimated symbols   126 running min
+ *   127 2pi hi   128:129 +-2pi   130,131 group-start phase/freq
  *   140:143 the phases of four consecutive steps (step k in v140 + k % 4) = their records
  */
 #ifndef QPSK_COSTAS_ASM_H
@@ -82,14 +82,14 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 
 /*
  * the same head with an independent instruction in four of its five empty issue slots: the 2*pi test of its phase
- * PIN and the previous step's leftovers -- its clamped frequency (-> FIN, this step's input) and its exact-zero
+ * PIN and the previous step's leftovers -- its frequency clamp (v118, in place: this step's input) and its exact-zero
  * test.  The head runs on the unwrapped PIN; LW (QPSK_WRAP_HEAD) wraps PIN in place, redoes the head, returns to LR.
  */
-#define QPSK_HEAD_DEFERRED(PIN, FIN, LW, LR)                                                                  \
+#define QPSK_HEAD_DEFERRED(PIN, LW, LR)                                                                      \
     "v_cvt_f64_f32 v[100:101], " PIN "\n\t"                                                                   \
     "v_cmp_ge_f32_e64 vcc, |" PIN "|, %[tau]\n\t"                                                             \
     "v_fma_f64 v[116:117], v[100:101], %[k2pi], %[magic]\n\t"                                                 \
-    "v_med3_f32 " FIN ", v118, %[fmin], %[fmax]\n\t"                                                          \
+    "v_med3_f32 v118, v118, %[fmin], %[fmax]\n\t"                                                             \
     "v_add_f64 v[104:105], v[116:117], -%[magic]\n\t"                                                         \
     "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
     "v_fma_f64 v[106:107], -v[104:105], %[hpi], v[100:101]\n\t"                                               \
@@ -100,10 +100,12 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 /*
  * the rest of a step: sin/cos polynomials -> T = symbol x conj(C + jS) -> detector -> loop update.  Leaves
  * T in v114:115 (with v116 from the head: the record), the unclamped frequency in v118, the new phase,
- * unwrapped, in POUT.  DREG = the VGPR pair holding this step's symbol, WAIT = the lgkmcnt wait in front of
+ * unwrapped, in POUT.  The two updates are v_fmac_f32 in its 4-byte encoding (s = +-1: the product is exact, so each is the
+ * reference's unfused multiply, then add): a lone wave's issue rate is set by instruction BYTES, ~1.56 per cycle
+ * (profiles/r03_ubench_fetch.txt: 4.15 cycles per 4-byte instruction, 5.14 per 8-byte one, 5.75 for v_fma_f32).  DREG = the VGPR pair holding this step's symbol, WAIT = the lgkmcnt wait in front of
  * its first use, READ = the LDS fetch of the pair after next (even steps) or nothing.
  */
-#define QPSK_BODY(PIN, FIN, POUT, DREG, WAIT, READ, QW)                                                       \
+#define QPSK_BODY(PIN, POUT, DREG, WAIT, READ, QW)                                                            \
     "v_fma_f64 v[110:111], v[108:109], %[c4], %[c3]\n\t"                                                      \
     "v_fma_f64 v[112:113], v[108:109], %[s3], %[s2]\n\t"                                                      \
     "v_fma_f64 v[110:111], v[108:109], v[110:111], %[c2]\n\t"                                                 \
@@ -124,9 +126,9 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
     "v_xor_b32_e32 v108, v114, v115\n\t"                      /* sign bit of s = sgn(T.x) sgn(T.y) */            \
     "v_pk_mul_f32 v[102:103], %[beal], v[106:107] op_sel_hi:[1,0]\n\t"   /* (beta d, alpha d) */                \
     "v_bfi_b32 v108, %[absm], 1.0, v108\n\t"                  /* s as +-1.0f */                                  \
-    "v_fma_f32 v118, v108, v102, " FIN "\n\t"                 /* freq + beta e */                                \
-    "v_add_f32_e32 v119, " PIN ", v118\n\t"                                                                   \
-    "v_fma_f32 " POUT ", v108, v103, v119\n\t"                /* (phase + freq) + alpha e */
+    "v_fmac_f32_e32 v118, v108, v102\n\t"                     /* freq + beta e (v118 = the clamped freq) */      \
+    "v_add_f32_e32 " POUT ", " PIN ", v118\n\t"                                                               \
+    "v_fmac_f32_e32 " POUT ", v108, v103\n\t"                 /* (phase + freq) + alpha e */
 
 /* the leftovers of a group's LAST step, in line: clamp -> FOUT, zero test, 2*pi test of POUT */
 #define QPSK_TAIL(POUT, FOUT, LW, LR)                                                                         \
@@ -177,14 +179,14 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
  * (odd k) or v135 (even k); SA/SB = the symbol sets of the first and the second pair, RD1/RD2 the fetches of the
  * two even steps, QOFF the byte offset of the four records, P4 where the fourth step leaves the next phase */
 #define QPSK_STEP_QUAD(SA_LO, SA_HI, SB_LO, SB_HI, RD1, RD2, QOFF, P4, L1, L2, L3, L4)                          \
-    QPSK_HEAD_DEFERRED("v140", "v135", "1" L1, "2" L1)                                                        \
-    QPSK_BODY("v140", "v135", "v141", SA_LO, QPSK_WAIT1, RD1, "")                                             \
-    QPSK_HEAD_DEFERRED("v141", "v133", "1" L2, "2" L2)                                                        \
-    QPSK_BODY("v141", "v133", "v142", SA_HI, "", "", "")                                                      \
-    QPSK_HEAD_DEFERRED("v142", "v135", "1" L3, "2" L3)                                                        \
-    QPSK_BODY("v142", "v135", "v143", SB_LO, QPSK_WAIT0, RD2, "")                                             \
-    QPSK_HEAD_DEFERRED("v143", "v133", "1" L4, "2" L4)                                                        \
-    QPSK_BODY("v143", "v133", P4, SB_HI, "", "", QPSK_QW(QOFF))
+    QPSK_HEAD_DEFERRED("v140", "1" L1, "2" L1)                                                        \
+    QPSK_BODY("v140", "v141", SA_LO, QPSK_WAIT1, RD1, "")                                             \
+    QPSK_HEAD_DEFERRED("v141", "1" L2, "2" L2)                                                        \
+    QPSK_BODY("v141", "v142", SA_HI, "", "", "")                                                      \
+    QPSK_HEAD_DEFERRED("v142", "1" L3, "2" L3)                                                        \
+    QPSK_BODY("v142", "v143", SB_LO, QPSK_WAIT0, RD2, "")                                             \
+    QPSK_HEAD_DEFERRED("v143", "1" L4, "2" L4)                                                        \
+    QPSK_BODY("v143", P4, SB_HI, "", "", QPSK_QW(QOFF))
 
 /*
  * Runs up to `groups` groups of COSTAS_ASM_GROUP steps starting at LDS addresses d_addr (symbols, 8 bytes each,
@@ -214,17 +216,18 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         "2:\n\t"
         "v_mov_b32 v130, %[p]\n\t"
         "v_mov_b32 v131, %[f]\n\t"
+        "v_mov_b32 v118, %[f]\n\t"            /* the frequency accumulates in place (v_fmac) */
         "v_mov_b32 v126, 0x7f800000\n\t"        /* running min of |T.x|, |T.y| over the group: 0 <=> some exact zero */
         "v_mov_b32 v140, %[p]\n\t"
         /* steps 0..3: the first has no predecessor in the group */
         QPSK_HEAD_CHAIN("v140")
-        QPSK_BODY("v140", "%[f]", "v141", "v[120:121]", QPSK_WAIT1, QPSK_RDB(16), "")
-        QPSK_HEAD_DEFERRED("v141", "v133", "101", "201")
-        QPSK_BODY("v141", "v133", "v142", "v[122:123]", "", "", "")
-        QPSK_HEAD_DEFERRED("v142", "v135", "102", "202")
-        QPSK_BODY("v142", "v135", "v143", "v[136:137]", QPSK_WAIT0, QPSK_RDA(32), "")
-        QPSK_HEAD_DEFERRED("v143", "v133", "103", "203")
-        QPSK_BODY("v143", "v133", "v140", "v[138:139]", "", "", QPSK_QW(0))
+        QPSK_BODY("v140", "v141", "v[120:121]", QPSK_WAIT1, QPSK_RDB(16), "")
+        QPSK_HEAD_DEFERRED("v141", "101", "201")
+        QPSK_BODY("v141", "v142", "v[122:123]", "", "", "")
+        QPSK_HEAD_DEFERRED("v142", "102", "202")
+        QPSK_BODY("v142", "v143", "v[136:137]", QPSK_WAIT0, QPSK_RDA(32), "")
+        QPSK_HEAD_DEFERRED("v143", "103", "203")
+        QPSK_BODY("v143", "v140", "v[138:139]", "", "", QPSK_QW(0))
         /* steps 4..15 */
         QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(48), QPSK_RDA(64), 16, "v140", "04", "05", "06", "07")
         QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(80), QPSK_RDA(96), 32, "v140", "08", "09", "10", "11")
@@ -336,17 +339,18 @@ __device__ __forceinline__ void costas_asm_run_ring(float &phase, float &freq, u
         "ds_read_b32 v125, %[ra]\n\t"
         "v_mov_b32 v130, %[p]\n\t"
         "v_mov_b32 v131, %[f]\n\t"
+        "v_mov_b32 v118, %[f]\n\t"            /* the frequency accumulates in place (v_fmac) */
         "v_mov_b32 v126, 0x7f800000\n\t"
         "v_mov_b32 v140, %[p]\n\t"
         /* steps 0..3; outstanding in front of the first pair's use: the last group's record write and the counter read */
         QPSK_HEAD_CHAIN("v140")
-        QPSK_BODY("v140", "%[f]", "v141", "v[120:121]", "s_waitcnt lgkmcnt(2)\n\t", QPSK_RDB(16), "")
-        QPSK_HEAD_DEFERRED("v141", "v133", "101", "201")
-        QPSK_BODY("v141", "v133", "v142", "v[122:123]", "", "", "")
-        QPSK_HEAD_DEFERRED("v142", "v135", "102", "202")
-        QPSK_BODY("v142", "v135", "v143", "v[136:137]", QPSK_WAIT0, QPSK_RDA(32), "")
-        QPSK_HEAD_DEFERRED("v143", "v133", "103", "203")
-        QPSK_BODY("v143", "v133", "v140", "v[138:139]", "", "", QPSK_QW(0))
+        QPSK_BODY("v140", "v141", "v[120:121]", "s_waitcnt lgkmcnt(2)\n\t", QPSK_RDB(16), "")
+        QPSK_HEAD_DEFERRED("v141", "101", "201")
+        QPSK_BODY("v141", "v142", "v[122:123]", "", "", "")
+        QPSK_HEAD_DEFERRED("v142", "102", "202")
+        QPSK_BODY("v142", "v143", "v[136:137]", QPSK_WAIT0, QPSK_RDA(32), "")
+        QPSK_HEAD_DEFERRED("v143", "103", "203")
+        QPSK_BODY("v143", "v140", "v[138:139]", "", "", QPSK_QW(0))
         QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(48), QPSK_RDA(64), 16, "v140", "04", "05", "06", "07")
         QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(80), QPSK_RDA(96), 32, "v140", "08", "09", "10", "11")
         QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(112), QPSK_RDN, 48, "%[p]", "12", "13", "14", "15")

@@ -15,9 +15,11 @@ constexpr int MAX_INDEX = 7;
 /* values a kernel stores in the context's status word (FusedArgs::status; api.cpp check_status) */
 constexpr int STATUS_PIPE_TIMEOUT = 1;   /* the in-LDS producer/consumer pipeline exhausted its bounded spins */
 constexpr int STATUS_PHASE_RANGE = 2;    /* a loop phase beyond the bounded 2 pi wrap (qpsk_device.h, phase_wrap) */
+constexpr int STATUS_NONFINITE = 3;      /* a loop ended on a NaN / Inf phase or frequency: the input held a non-finite sample */
 
 struct FusedArgs {
-    const float2 *x;        /* [nframes][frame_size] */
+    const float2 *x;        /* [nframes] frames of frame_size samples, frame_pitch samples apart */
+    size_t frame_pitch;     /* >= frame_size (qpsk_rx_batch: = frame_size) */
     int nframes, frame_size, cycles, nsym;
     int G, S;               /* frames per workgroup, symbols per chunk */
     int mixed;              /* rx_fused_pipe_kernel, set by its launcher: 0 = every FIR wave filters 4 frames, 4 symbols per

@@ -90,7 +90,7 @@ rx_fused_kernel(FusedArgs a)
             const int n = base + w;
             float2 v = make_float2(0.0f, 0.0f);
             if (n >= 0 && n < L)
-                v = a.x[(size_t)(f0 + g) * L + n];
+                v = a.x[(size_t)(f0 + g) * a.frame_pitch + n];
             xs[(size_t)g * W + w] = v;
         }
         __syncthreads();
@@ -151,6 +151,8 @@ rx_fused_kernel(FusedArgs a)
             a.state_out[2 * o + 1] = st.freq;
         }
         if (over && a.status) __hip_atomic_store(a.status, STATUS_PHASE_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else if (a.status && !loop_state_finite(st.phase, st.freq))
+            __hip_atomic_store(a.status, STATUS_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -516,6 +518,8 @@ costas_kernel(const float2 *__restrict__ d, int nframes, int nsym, int dstride, 
     }
     if (state_out) { state_out[2 * t] = st.phase; state_out[2 * t + 1] = st.freq; }
     if (over && status) __hip_atomic_store(status, STATUS_PHASE_RANGE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (status && !loop_state_finite(st.phase, st.freq))
+        __hip_atomic_store(status, STATUS_NONFINITE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* ========================================================================

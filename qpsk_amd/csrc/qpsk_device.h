@@ -232,5 +232,14 @@ __device__ __forceinline__ void costas_step_t(float &phase, float &freq, float a
     freq = f;
 }
 
+/* NaN / Inf inputs are fenced, not reproduced: a non-finite sample reaches its loop through the filter and the loop state
+ * then stays non-finite to the end of the frame (phase = phase + ...), where the kernel flags the call (STATUS_NONFINITE ->
+ * QPSK_ERR_RANGE).  The reference itself spins forever in phase_wrap() on an infinite phase (costas_loop.c:61-67) and goes
+ * through __mulsc3's recovery on NaN products (qpsk.c:197), which this library does not restate. */
+__device__ __forceinline__ bool loop_state_finite(float phase, float freq)
+{
+    return fabsf(phase) <= 3.402823466e+38f && fabsf(freq) <= 3.402823466e+38f;
+}
+
 } // namespace qpsk
 #endif

@@ -228,7 +228,13 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
 #ifdef QPSK_PIPE_PROFILE
     /* dbg bit 12 (4096): keep the ring stream under dbg 32 and time it (cycles inside the stream / waiting outside it) */
     const bool ring_prof = (a.dbg & 4096) != 0 && (blockIdx.x == 0 || blockIdx.x == 77);
-    unsigned long long rp_in = 0, rp_out = 0, rp_t = 0, rp_calls = 0;
+    unsigned long long rp_in = 0, rp_out = 0, rp_t = 0, rp_calls = 0, rp_rt0 = 0, rp_rt1 = 0, rp_rt2 = 0;
+    auto rp_real = [&]() {      /* the 100 MHz constant clock: wall time inside the launch */
+        unsigned long long t = 0;
+        if (ring_prof) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+    rp_rt0 = rp_real();
     auto rp_tick = [&](unsigned long long &acc) {
         if (ring_prof) {
             unsigned long long t;
@@ -263,11 +269,12 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
                         unsigned ks = __builtin_amdgcn_readfirstlane(k);
 #ifdef QPSK_PIPE_PROFILE
                         rp_tick(rp_out);
-                        rp_calls++;
+                        if (rp_calls++ == 0) rp_rt1 = rp_real();
 #endif
                         costas_asm_run_ring(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kend, al, be, fmin_, fmax_, fl);
 #ifdef QPSK_PIPE_PROFILE
                         rp_tick(rp_in);
+                        rp_rt2 = rp_real();
 #endif
                         k = ks;
                     }
@@ -373,8 +380,9 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
         printf("serial wave: %d chunks; cycles per chunk: wait for the FIR waves %llu, steps %llu\n", nchunks, cw / nchunks, cs / nchunks);
     if (ring_prof && lane == 0)
         printf("wg %3d serial wave: %d chunks, %llu entries into the stream; cycles per chunk inside the stream %llu (= %llu per step), "
-               "outside it (waiting for the FIR waves, redone groups) %llu\n", (int)blockIdx.x, nchunks, rp_calls, rp_in / nchunks,
-               rp_in / nchunks / S, rp_out / nchunks);
+               "outside it (waiting for the FIR waves, redone groups) %llu; wall time (100 MHz clock): wave start -> first step %.2f us, "
+               "first -> last step %.2f us\n", (int)blockIdx.x, nchunks, rp_calls, rp_in / nchunks,
+               rp_in / nchunks / S, rp_out / nchunks, (double)(rp_rt1 - rp_rt0) * 0.01, (double)(rp_rt2 - rp_rt1) * 0.01);
 #endif
     st.phase = ph; st.freq = fr;
     if (active && ok) {
@@ -386,6 +394,7 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
     }
     if (!ok && lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
     if (over) report_status(status, STATUS_PHASE_RANGE);
+    else if (active && ok && !loop_state_finite(ph, fr)) report_status(status, STATUS_NONFINITE);
 }
 
 /*
@@ -653,7 +662,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
             cx.h0[ff] = p0 >= 128;                            /* position p0 - 128 of the next chunk's window exists */
             cx.h1[ff] = p0 + 1 >= 128;
             cx.hist[ff] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   /* a fresh delay line (qpsk.c:37) */
-            cx.src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(cx.fv[ff] ? fr : 0) * L);
+            cx.src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(cx.fv[ff] ? fr : 0) * a.frame_pitch);
         }
         return cx;
     };
@@ -1007,7 +1016,7 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
             U.fv[ff] = UF * U.u + ff < G && fr < a.nframes;      /* an odd G leaves the last unit one frame */
             const int ix = a.index ? (U.fv[ff] ? a.index[fr] : 0) : a.fixed_index;   /* decimation offset, < C */
             U.ix[ff] = __builtin_amdgcn_readfirstlane(ix);
-            U.src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(U.fv[ff] ? fr : 0) * L);
+            U.src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(U.fv[ff] ? fr : 0) * a.frame_pitch);
             U.hist[ff] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       /* a fresh delay line (qpsk.c:37) */
         }
     }
@@ -1409,7 +1418,7 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
             w.wr0[ui][ff] = lds_addr(mywin + ff * WS + slot_of(p0)) - 8u * BLK;
             w.wr1[ui][ff] = lds_addr(mywin + ff * WS + slot_of(p0 + 1)) - 8u * BLK;
             if (lane == 0) {
-                const unsigned long long src = (unsigned long long)(a.x + (size_t)fr * L);
+                const unsigned long long src = (unsigned long long)(a.x + (size_t)fr * a.frame_pitch);
                 prm[4 * ui + 2 * ff] = (unsigned)src;
                 prm[4 * ui + 2 * ff + 1] = (unsigned)(src >> 32);
             }
@@ -1448,6 +1457,16 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
             printf("wg %3d FIR wave hw %2d (%d units): %d chunks, %llu cycles in the stream; per chunk: samples %u, stage+loads %u, "
                    "filter+gain %u, wait for the loop %u, flush %u, hand-over %u\n", (int)blockIdx.x, hwave, NUW, nchunks, t1 - t0,
                    pf[0] / nchunks, pf[1] / nchunks, pf[2] / nchunks, pf[3] / nchunks, pf[4] / nchunks, pf[5] / nchunks);
+    } else if (a.dbg & (1 | 16384 | 32768)) {
+        /* measurement build: streams with a part of the work left out (WRONG results): 1 the filter's multiplies and adds,
+         * 16384 its window reads, 32768 the flush's arithmetic -- what each costs in time at the board's power limit */
+#define QPSK_LEAN_ABLATED(SFX)                                                                                          \
+        (NUW == 2 ? fir_lean_loop2_##SFX(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w)    \
+                  : fir_lean_loop1_##SFX(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w))
+        if (a.dbg & 1) st = QPSK_LEAN_ABLATED(avalu);
+        else if (a.dbg & 16384) st = QPSK_LEAN_ABLATED(alds);
+        else st = QPSK_LEAN_ABLATED(aflush);
+#undef QPSK_LEAN_ABLATED
     } else
 #endif
     if constexpr (NUW == 2)
@@ -1455,15 +1474,16 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
     else
         st = fir_lean_loop1(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w);
     bool ok = st == 0;
-    if (ok) {
-        ok = wait_ge(&sm->consumed, nchunks, &sm->abort_flag);
-        if (ok)
+    if (ok) {      /* the last two chunks leave as the loop finishes each (the first while it still steps through the second) */
+        for (int c = nchunks - DR; c < nchunks && ok; c++) {
+            ok = wait_ge(&sm->consumed, c + 1, &sm->abort_flag);
+            if (ok)
 #pragma unroll
-            for (int ui = 0; ui < NUW; ui++) {
-                const int g = UF * (u0 + ui) + fl;
-                for (int c = nchunks - DR; c < nchunks; c++)
+                for (int ui = 0; ui < NUW; ui++) {
+                    const int g = UF * (u0 + ui) + fl;
                     flush_records<GM, R>(a, zring, dring, g, f0 + g, q, c);
-            }
+                }
+        }
     } else if (lane == 0) {
         __hip_atomic_store(&sm->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }

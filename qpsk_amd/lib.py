@@ -46,7 +46,7 @@ API_SYMBOLS = [
     "qpsk_last_error", "qpsk_version", "qpsk_device_count", "qpsk_params_default", "qpsk_ctx_create",
     "qpsk_ctx_destroy", "qpsk_ctx_sync", "qpsk_ctx_set_stream", "qpsk_ctx_set_tuning", "qpsk_ctx_cycles", "qpsk_ctx_nsym",
     "qpsk_ctx_last_kernel",
-    "qpsk_ctx_get_taps", "qpsk_ctx_get_gains", "qpsk_ctx_set_taps", "qpsk_ctx_set_loop", "qpsk_rx_batch",
+    "qpsk_ctx_get_taps", "qpsk_ctx_get_gains", "qpsk_ctx_set_taps", "qpsk_ctx_set_loop", "qpsk_rx_batch", "qpsk_rx_batch_pitched",
     "qpsk_rx_batch_bw", "qpsk_rrc_fir_batch", "qpsk_timing_hist_batch", "qpsk_timing_scan_batch", "qpsk_timing_fft_batch", "qpsk_costas_batch", "qpsk_fft_batch",
     "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
     "qpsk_streams_rx_pcm", "qpsk_streams_rx_pcm_host", "qpsk_dev_alloc", "qpsk_dev_free", "qpsk_dev_upload", "qpsk_dev_download",
@@ -101,6 +101,7 @@ def load():
     L.qpsk_ctx_set_taps.argtypes = [vp, C.POINTER(f32)]
     L.qpsk_ctx_set_loop.argtypes = [vp, f32, f32, f32, f32]
     L.qpsk_rx_batch.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.qpsk_rx_batch_pitched.argtypes = [vp, vp, C.c_longlong, i32, vp, vp, vp, vp, vp, vp]
     L.qpsk_rx_batch_bw.argtypes = [vp, vp, i32, C.POINTER(f32), i32, vp, vp, vp, vp]
     L.qpsk_rrc_fir_batch.argtypes = [vp, vp, vp, vp, i32, i32]
     L.qpsk_timing_hist_batch.argtypes = [vp, vp, i32, vp, vp]
@@ -240,9 +241,12 @@ class Modem:
                                          _ptr(o.get("costas")), _ptr(o.get("index")), _ptr(o.get("hz"))))
         return o
 
-    def rx_batch_raw(self, x, F, sym, freq, phase):
-        """No allocation, no checks: the call bench.py times."""
-        rc = self.L.qpsk_rx_batch(self.h, _ptr(x), F, _ptr(sym), _ptr(freq), _ptr(phase), None, None, None)
+    def rx_batch_raw(self, x, F, sym, freq, phase, pitch=0):
+        """No allocation, no checks: the call bench.py times.  pitch: complex samples between frame starts (0 = packed)."""
+        if pitch:
+            rc = self.L.qpsk_rx_batch_pitched(self.h, _ptr(x), pitch, F, _ptr(sym), _ptr(freq), _ptr(phase), None, None, None)
+        else:
+            rc = self.L.qpsk_rx_batch(self.h, _ptr(x), F, _ptr(sym), _ptr(freq), _ptr(phase), None, None, None)
         if rc:
             self._check(rc)
 

@@ -940,6 +940,75 @@ def test_huge_amplitude_is_an_error_not_a_hang(oracle, generic):
     assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
 
 
+@pytest.mark.parametrize("kernel", ["pipe", "lean", "generic"])
+@pytest.mark.parametrize("bad", ["nan", "inf", "-inf"])
+def test_nonfinite_input_is_an_error(oracle, kernel, bad):
+    """NaN / Inf samples are fenced: the call RETURNS (no wave spins: every wait and wrap is bounded) and
+    fails with QPSK_ERR_RANGE at the next synchronisation -- a NaN keeps its loop's state NaN to the end of the frame
+    (STATUS_NONFINITE), an infinity runs into the bounded 2 pi wrap (STATUS_PHASE_RANGE; the reference hangs there,
+    costas_loop.c:61-67).  The frames WITHOUT such a sample in the same call still carry the oracle's bits, and the context
+    stays usable."""
+    import qpsk_amd
+    fs, rs = 19200.0, 2400.0
+    L, F = (1024, 64) if kernel != "lean" else (1024, 512)       # lean: whole even workgroups of whole 64-symbol chunks
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    if kernel == "generic":
+        m.tune(fused_generic=1)
+    if kernel == "lean":
+        m.tune(pipe_v=3)
+    x, _ = make_frames(F, L, 8, m.taps, fs, base_seed=31, noise=0.02)
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=6)
+    xb = x.copy()
+    hit = [3, F // 2 + 1]
+    xb[hit[0], 300, 0] = np.float32(bad)
+    xb[hit[1], L - 5, 1] = np.float32(bad)
+    got = m.rx_batch(xb)
+    with pytest.raises(qpsk_amd.QpskError, match="-6"):
+        m.sync()
+    if kernel == "lean":
+        assert m.last_kernel() == "rx_lean_kernel"
+    clean = [f for f in range(F) if f not in hit]
+    for k in ("sym", "phase", "freq"):
+        assert bits_equal(got[k].cpu().numpy()[clean], want[k][clean]), k
+    # symbols of a hit frame before the sample's first filter output are untouched too
+    assert bits_equal(got["sym"].cpu().numpy()[hit[0], :(300 - 6) // 8 - 1], want["sym"][hit[0], :(300 - 6) // 8 - 1])
+    got = m.rx_batch(x)
+    m.sync()
+    assert_batch_equal(got, want, keys=("sym", "phase", "freq"))
+
+
+@pytest.mark.parametrize("kernel,L,F,extra", [("pipe", 1024, 40, 64), ("lean", 1024, 512, 512), ("lean", 2048, 96, 34), ("generic", 1000, 9, 2)])
+def test_pitched_frames(oracle, kernel, L, F, extra):
+    """qpsk_rx_batch_pitched: frames frame_size + extra samples apart (the gap filled with NaN: never read) give the packed
+    call's bits on every receive kernel; a pitch below frame_size, an odd pitch on the pipeline kernels' path and a pitch
+    with an estimating timing mode are refused."""
+    import torch
+    import qpsk_amd
+    fs, rs = 19200.0, 2400.0
+    cyc = 8 if kernel != "generic" else 5
+    fs = rs * cyc
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=3)
+    if kernel == "lean":
+        m.tune(pipe_v=3)
+    x, _ = make_frames(F, L, cyc, m.taps, fs, base_seed=77, noise=0.03)
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=3)
+    buf = torch.full((F, L + extra, 2), float("nan"), dtype=torch.float32, device="cuda")
+    buf[:, :L] = torch.from_numpy(x).cuda()
+    sym = torch.zeros((F, m.nsym), dtype=torch.uint8, device="cuda")
+    fr = torch.zeros((F,), dtype=torch.float32, device="cuda")
+    ph = torch.zeros_like(fr)
+    m.rx_batch_raw(buf, F, sym, fr, ph, pitch=L + extra)
+    m.sync()
+    if kernel == "lean":
+        assert m.last_kernel() == "rx_lean_kernel"
+    assert_batch_equal(dict(sym=sym, freq=fr, phase=ph), want, keys=("sym", "phase", "freq"))
+    with pytest.raises(qpsk_amd.QpskError, match="frame_pitch"):
+        m.rx_batch_raw(buf, F, sym, fr, ph, pitch=L - 2)
+    mh = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_HIST)
+    with pytest.raises(qpsk_amd.QpskError, match="QPSK_TIMING_FIXED"):
+        mh.rx_batch_raw(buf, F, sym, fr, ph, pitch=L + extra)
+
+
 def test_caller_stream_ordering_contract(oracle):
     """include/qpsk_hip.h, "Stream ordering": the library enqueues on the context's stream and nothing else orders it
     against the caller's other streams.  Here the context runs on a NON-default torch stream, buffers are produced and

@@ -59,6 +59,36 @@ def test_independent_frames_match_reference(oracle, name, kind):
         assert r["phase"] == o["phase"][f] and r["freq"] == o["freq"][f] and r["hz"] == o["hz"][f]
 
 
+def _same_with_nans(a, b):
+    """bit-equal where finite; NaN where the other is NaN (a NaN's sign and payload depend on operand order, which the
+    oracle's component-wise complex products and the compiler's __mulsc3 calls need not share)"""
+    a, b = np.asarray(a, np.float32).ravel(), np.asarray(b, np.float32).ravel()
+    na, nb = np.isnan(a), np.isnan(b)
+    return a.shape == b.shape and np.array_equal(na, nb) and bits_equal(a[~na], b[~nb])
+
+
+@pytest.mark.parametrize("where", [0, 700, 2047])
+def test_nan_input_matches_reference(oracle, where):
+    """A NaN sample: the reference's complex products go through __mulsc3 (qpsk.c:197, 114-118), whose
+    recovery branch only acts on INFINITE operands, so for NaN inputs the oracle's component-wise arithmetic gives the
+    reference's values: the same symbols, the same finite values before the NaN reaches the loop, NaN in the same places
+    after.  (An infinite sample is not compared: the reference's phase_wrap() never returns from an infinite phase,
+    costas_loop.c:61-67 -- the library fences both, tests/test_gpu_parity.py::test_nonfinite_input_is_an_error.)"""
+    ref = Reference("c1small")
+    ref.reset()
+    L = ref.frame_size
+    x, _ = make_frames(3, L, ref.cycles, ref.taps(), ref.fs, offset_hz=40.0, base_seed=11, noise=0.05)
+    x[1, min(where, L - 1), 0] = np.float32("nan")
+    o = oracle.rx_batch(x, ref.fs, ref.rs, loop_bw=BW, timing_mode=TIMING_HIST, want_costas=True)
+    for f in range(3):
+        r = ref.independent_frame(x[f], loop_bw=BW)
+        assert bits_equal(r["sym"], o["sym"][f])
+        assert _same_with_nans(r["costas"], o["costas"][f])
+        assert _same_with_nans([r["phase"], r["freq"], r["hz"]], [o["phase"][f], o["freq"][f], o["hz"][f]])
+    # the frame's last sample only reaches a decimated symbol when the timing offset is CYCLES - 1: no NaN anywhere otherwise
+    assert (np.isnan(o["phase"][1]) or where >= L - 1) and not np.isnan(o["phase"][0]) and not np.isnan(o["phase"][2])
+
+
 def test_loop_bandwidth_sweep_matches_reference(oracle):
     ref = Reference("c5small")
     ref.reset()

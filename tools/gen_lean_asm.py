@@ -59,6 +59,10 @@ WS_SLOTS = 712                         # slots per frame window (rx_fused.hip, l
 # measurement variant (--profile -> fir_lean_prof_asm.h, only compiled into the -DQPSK_PIPE_PROFILE library): shader cycles per
 # phase of a unit, accumulated in v160..v165 (v166 scratch, v167 the last stamp) and handed back through six outputs
 PROFILE = False
+# measurement-only streams with a part of the work left out (wrong results; the profile header only): what each part costs in
+# TIME at the board's power limit, i.e. in energy.  "valu": no filter multiplies / adds; "lds": no window reads after the first
+# two blocks; "flush": no sin/cos redo, rotation, slicer arithmetic
+ABLATE = None
 NPROF = 6            # wait for the samples | stage + issue loads | filter + gain | wait for the loop | flush | hand-over + priority
 PACC, PTMP, PLAST = 160, 166, 167
 
@@ -66,7 +70,7 @@ PACC, PTMP, PLAST = 160, 166, 167
 def stamp(e, k):
     """close phase k: cycles since the last stamp -> accumulator k (the SMEM read shares lgkmcnt with LDS: the wait also drains
     the wave's LDS operations, which the next phase would have waited for in order anyway)"""
-    if not PROFILE:
+    if not PROFILE or ABLATE:
         return
     e("s_memtime %s", sp(ST2))
     e("s_waitcnt lgkmcnt(0)")
@@ -150,15 +154,21 @@ def filter_stream(e, packed=True):
     the serial wave on the idea that a single-float instruction holds the SIMD for 2 cycles; it holds it for 4 like a packed
     one, so twice the instructions cost the serial wave twice the cycles: 0.316 against 0.275 ms at 8192 frames."""
     reads = {}
+    nolds = ABLATE == "lds"
     for d in range(min(DEPTH, NB)):
         reads[d] = fetch(e, d)
-    e("v_mov_b64 %s, 0", vp(ACC))
-    e("v_mov_b64 %s, 0", vp(ACC + 2))
+    if ABLATE == "valu":        # a plausible symbol instead of the sum (a zero would send the loop to its exact-zero path)
+        for i in range(2):
+            e("v_mov_b32_e32 v%d, 0x3f333333", ACC + 2 * i)
+            e("v_mov_b32_e32 v%d, 0x3e99999a", ACC + 2 * i + 1)
+    else:
+        e("v_mov_b64 %s, 0", vp(ACC))
+        e("v_mov_b64 %s, 0", vp(ACC + 2))
     acc = [ACC, ACC + 2]
     nmul = 0
     for b in range(NB):
         if b + DEPTH < NB:
-            reads[b + DEPTH] = fetch(e, b + DEPTH)
+            reads[b + DEPTH] = fetch(e, b + DEPTH) if not (nolds and b + DEPTH >= NW) else 0
         later = sum(reads.get(x, 0) for x in range(b + 1, min(NB, b + DEPTH + 1)))
         e("s_waitcnt lgkmcnt(%d)", later)
         for u in range(0, C, 2):
@@ -183,8 +193,9 @@ def filter_stream(e, packed=True):
                                 adds.append("v_add_f32_e32 v%d, v%d, v%d" % (acc[sym] + h, acc[sym] + h, p + h))
                         np_ += 1
                         nmul += 1
-            for x in muls + adds:
-                e(x)
+            if ABLATE != "valu":
+                for x in muls + adds:
+                    e(x)
     assert nmul == 254
     return nmul
 
@@ -287,6 +298,11 @@ def flush(e, ui):
     e("ds_read_b64 %s, v%d", vp(FL), TMP + 3)
     e("ds_read_b128 %s, v%d", v4(FL + 2), TMP + 2)
     e("s_waitcnt lgkmcnt(0)")
+    if ABLATE == "flush":
+        e("global_store_short %%[symoff], v%d, %s", FL, sp(SYMB + 2 * ui))
+        e("s_add_u32 s%d, s%d, 64", SYMB + 2 * ui, SYMB + 2 * ui)
+        e("s_addc_u32 s%d, s%d, 0", SYMB + 2 * ui + 1, SYMB + 2 * ui + 1)
+        return
     sincos_pair(e, PH, b)
     for k in range(2):
         B = b[k]
@@ -446,6 +462,7 @@ def block(nuw, packed=True):
     e("v_readfirstlane_b32 s%d, v%d", SIX, PRE + 13)
     e("v_readfirstlane_b32 s%d, v%d", ST0, PRE + 16)
     e("v_readfirstlane_b32 s%d, v%d", ST1, PRE + 17)
+    loads(e, 0)                 # the first unit's samples at once: their HBM latency covers the tap loads and the set-up below
     for i in range(4):
         e("s_load_dwordx16 s[%d:%d], %s, 0x%x", TAP0 + 16 * i, TAP0 + 16 * i + 15, sp(ST0), 64 * i)
     for reg, bits in CONSTS.items():
@@ -457,8 +474,7 @@ def block(nuw, packed=True):
     e("s_mov_b32 s%d, 0", SC)
     e("s_mov_b32 s%d, 0", SFL)
     e("s_waitcnt lgkmcnt(0)")                                  # the taps
-    loads(e, 0)
-    if PROFILE:
+    if PROFILE and not ABLATE:
         for k in range(NPROF):
             e("v_mov_b32_e32 v%d, 0", PACC + k)
         stamp(e, -1)
@@ -477,7 +493,7 @@ def block(nuw, packed=True):
     e.place("Lexit_%=")
     e("s_setprio 0")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    if PROFILE:
+    if PROFILE and not ABLATE:
         for k in range(NPROF):
             e("v_mov_b32_e32 %%[pf%d], v%d", k, PACC + k)
     return e.lines
@@ -493,10 +509,11 @@ def emit_function(nuw, packed=True):
         for ff in range(2):
             ops += ['[w0_%d%d] "v"(w.wr0[%d][%d])' % (ui, ff, ui, ff), '[w1_%d%d] "v"(w.wr1[%d][%d])' % (ui, ff, ui, ff)]
         ops += ['[ring%d] "v"(w.ring[%d])' % (ui, ui), '[z%d] "v"(w.z[%d])' % (ui, ui)]
-    vlast = PLAST if PROFILE else VLAST
+    vlast = PLAST if PROFILE and not ABLATE else VLAST
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"v%d"' % r for r in range(PRE, vlast + 1)] + ['"s%d"' % r for r in list(range(SRC, 32)) + list(range(35, TAP0 + 64))]
     nvalu = sum(1 for ln in lines if ln.startswith("v_"))
-    outs = ['[status] "=s"(status)'] + (['[pf%d] "=&v"(prof[%d])' % (k, k) for k in range(NPROF)] if PROFILE else [])
+    stamped = PROFILE and not ABLATE
+    outs = ['[status] "=s"(status)'] + (['[pf%d] "=&v"(prof[%d])' % (k, k) for k in range(NPROF)] if stamped else [])
     return '''
 /* %(nuw)d unit(s) per wave%(how)s: %(n)d instructions, %(nvalu)d of them vector ALU */
 __device__ __forceinline__ int fir_lean_loop%(nuw)d%(sfx)s(%(args)s, const LeanLaneAddr &w%(parg)s)
@@ -511,8 +528,8 @@ __device__ __forceinline__ int fir_lean_loop%(nuw)d%(sfx)s(%(args)s, const LeanL
 }
 ''' % dict(nuw=nuw, n=len([ln for ln in lines if not ln.endswith(":")]), nvalu=nvalu, args=", ".join(args), body=body,
            ops=",\n          ".join(ops), clob=", ".join(clob), outs=",\n          ".join(outs),
-           sfx=("" if packed else "u") + ("_prof" if PROFILE else ""),
-           how="" if packed else ", the filter in single-float instructions (the wave beside the serial wave)", parg=", unsigned (&prof)[%d]" % NPROF if PROFILE else "")
+           sfx=("" if packed else "u") + ("_a" + ABLATE if ABLATE else "_prof" if PROFILE else ""),
+           how="" if packed else ", the filter in single-float instructions (the wave beside the serial wave)", parg=", unsigned (&prof)[%d]" % NPROF if stamped else "")
 
 
 def main_profile():
@@ -531,6 +548,11 @@ constexpr int FIR_LEAN_NPROF = %d;
 ''' % NPROF)
     print(emit_function(1))
     print(emit_function(2))
+    global ABLATE
+    for ABLATE in ("valu", "lds", "flush"):
+        print(emit_function(1))
+        print(emit_function(2))
+    ABLATE = None
     print("} // namespace qpsk\n#endif")
 
 
