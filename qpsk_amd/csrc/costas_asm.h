@@ -300,6 +300,16 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
  * Registers: as costas_asm_run, plus v132 / v134 / v124 = symbol address, record address, address of the next
  * group's first symbol pair, v125 = the counter read.
  */
+/* INVARIANT of the ring stream's LDS traffic (nothing checks it at compile time -- keep it when editing; the test
+ * test_stream_across_ring_handovers_takes_its_fallbacks exercises every hand-over): LDS operations of a wave complete in
+ * issue order and lgkmcnt counts them, so the wait in front of a group's first symbol use, `s_waitcnt lgkmcnt(2)`, is right
+ * exactly while at most TWO LDS operations are issued between the fetch of that group's first pair (QPSK_RDN, in step 14
+ * of the group before) and the wait: the last record write of that group (QPSK_QW(48), step 15) and this group's counter
+ * read (ds_read_b32 v125).  The optional `consumed` write at a chunk boundary sits between them in program order only on
+ * paths that LEAVE the stream or re-enter at label 2 after it -- there three operations follow the fetch and the wait
+ * lets two of them stay outstanding, i.e. it still covers the fetch (the oldest).  One more LDS instruction anywhere
+ * between QPSK_RDN and that wait needs lgkmcnt(3), one fewer lgkmcnt(1); no ordering fence is needed for the hand-over
+ * itself (counter read before data reads, data writes before counter write, same wave, in order). */
 #define QPSK_DA "v132"
 #define QPSK_ZA "v134"
 #define QPSK_RDN "ds_read_b128 v[120:123], v124\n\t"

@@ -58,6 +58,11 @@
 
 namespace qpsk {
 
+/* register budgets of the generated streams (tools/gen_fir_asm.py, tools/gen_lean_asm.py): kernels with three waves per
+ * SIMD have 168 VGPRs; the serial wave's stream (costas_asm.h) owns v100..v143 of its own wave only */
+static_assert(FIR_R2_ASM_END_VGPR <= 168, "rx_pipe2_kernel: three FIR waves per SIMD");
+static_assert(FIR_R4_ASM_END_VGPR <= 256, "rx_fused_pipe_kernel: two waves per SIMD");
+
 namespace pipe {
 
 constexpr int C = 8;            /* CYCLES this instantiation is built for */

@@ -31,6 +31,7 @@
 #include "qpsk_device.h"
 #include "costas_asm.h"      /* lds_addr() */
 #include "fir_full8_asm.h"
+static_assert(qpsk::FIR_FULL8_ASM_END_VGPR <= 168, "timing_scan_kernel: 12 waves per workgroup = three per SIMD = at most 168 VGPRs (regenerate fir_full8_asm.h from VGPR 80, tools/gen_fir_asm.py)");
 #include "kernels.h"
 
 namespace qpsk {

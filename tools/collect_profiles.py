@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
 SRC = os.path.join(ROOT, "gpurun_out")
-HOT = "rx_fused_pipe_kernel"     # config 2 (16-frame workgroups); 8192-frame shards run rx_pipe2_kernel
+HOT = "rx_fused_pipe_kernel"     # config 2 (16-frame workgroups); 8192-frame shards run rx_lean_kernel
 
 
 def qpsk_rows(path):
@@ -31,7 +31,17 @@ def qpsk_rows(path):
         return rd.fieldnames, rows
 
 
+def failed(sub):
+    """tools/measure_all.sh leaves <pass>.failed behind when a pass did not complete"""
+    if os.path.exists(os.path.join(SRC, sub + ".failed")):
+        print("SKIPPED %s: the pass failed (gpurun_out/%s.failed)" % (sub, sub))
+        return True
+    return False
+
+
 def copy_stats(tag, sub, name):
+    if failed(sub):
+        return
     found = sorted(glob.glob(os.path.join(SRC, sub, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if not found:
         return
@@ -45,6 +55,8 @@ def copy_stats(tag, sub, name):
 
 def pmc(sub, counter, hot=HOT):
     vals, rows_out, fields = [], [], None
+    if failed(sub):
+        return vals, rows_out, fields
     found = sorted(glob.glob(os.path.join(SRC, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     for p in found[-1:]:                      # the newest run only
         with open(p) as f:
@@ -92,7 +104,7 @@ def main():
         copy_stats(tag, sub, name)
     shapes = {}
     for key, fsub, wsub, hot, frames in (("4096x16384", "pmc_fetch", "pmc_write", "rx_fused_pipe_kernel", 4096),
-                                         ("8192x16384", "pmc_fetch_8192", "pmc_write_8192", "rx_pipe2_kernel", 8192)):
+                                         ("8192x16384", "pmc_fetch_8192", "pmc_write_8192", "rx_lean_kernel", 8192)):
         e = traffic_entry(tag, fsub, wsub, hot, frames, 16384, "%s_pmc_fetch_write_%d.csv" % (tag, frames))
         if e:
             shapes[key] = e

@@ -5,7 +5,9 @@ evaluated at the decimated outputs a lane owns).
 
     python tools/gen_fir_asm.py 1 100 2 > qpsk_amd/csrc/fir_r2_asm.h      # depth, first VGPR, R [, step]
     python tools/gen_fir_asm.py 1 144 4 > qpsk_amd/csrc/fir_r4_asm.h
-    python tools/gen_fir_asm.py 1 144 8 1 > qpsk_amd/csrc/fir_full8_asm.h  # full rate: 8 CONSECUTIVE outputs per lane
+    python tools/gen_fir_asm.py 1 80 8 1 > qpsk_amd/csrc/fir_full8_asm.h   # full rate: 8 CONSECUTIVE outputs per lane (v80..v167:
+                                                                            # timing_scan_kernel runs three waves per SIMD, 168 VGPRs)
+The committed headers are checked against these command lines by tests/test_generated_headers.py.
 
 Why a generated stream and not C++: the compiler's version of the same sum (asm-pinned product/add order) carries
 ~60 v_mov and ~60 s_nop per 508 packed multiply/adds, and fetches LDS only one block of 8 window positions ahead --
