@@ -171,6 +171,13 @@ int qpsk_rx_batch_bw(qpsk_ctx *ctx, const float *d_in, int nframes, const float 
  *   fits the library's staging (it copies first); prefer separate buffers. */
 int qpsk_rrc_fir_batch(qpsk_ctx *ctx, float *d_memory, const float *d_in, float *d_out, int nframes, int length);
 
+/* The same filter by overlap-save with 512-point FFTs (algorithms/fft.h:44) -- FAST, NOT EXACT: the
+ * transform changes the summation order of rrc_fir.c:22-26, so the output agrees with qpsk_rrc_fir_batch to ~1e-6 of the
+ * frame's peak (bounds asserted in tests/test_gpu_parity.py::test_rrc_fir_fast_error_bounds), not bit for bit.  The
+ * library itself never uses it: qpsk_rx_batch and the streams keep the exact kernels, whose symbols sit on decision
+ * boundaries.  d_out must not alias d_in; d_memory as above (updated exactly: it is a copy of input samples). */
+int qpsk_rrc_fir_batch_fast(qpsk_ctx *ctx, float *d_memory, const float *d_in, float *d_out, int nframes, int length);
+
 /* timing histogram (qpsk.c:127-180) of nframes filtered blocks -> d_index[nframes]; d_hist, if not NULL,
  * receives hist_i[k] + hist_q[k], k = 0..7 (qpsk.c:175, locals of rx_frame) as [nframes][8] */
 int qpsk_timing_hist_batch(qpsk_ctx *ctx, const float *d_filtered, int nframes, int32_t *d_index, int32_t *d_hist);

@@ -109,6 +109,8 @@ struct qpsk_ctx {
     DevBuf index, filtered, mixed, keystream;
     int keystream_len = 0;
     std::map<int, double *> twiddles;
+    float *d_fast = nullptr;      /* qpsk_rrc_fir_batch_fast: H[512][2] then tw[512][2]; rebuilt when the taps change */
+    bool fast_valid = false;
     /* streams */
     int nstreams = 0;
     float *s_memory = nullptr, *s_dec = nullptr, *s_loop = nullptr, *s_mixer = nullptr;
@@ -312,6 +314,7 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
     hipFree(c->mixed.p);
     hipFree(c->keystream.p);
     for (auto &kv : c->twiddles) hipFree(kv.second);
+    hipFree(c->d_fast);
     free_streams(c);
     free_transmitters(c);
     delete c;
@@ -369,6 +372,7 @@ int qpsk_ctx_set_taps(qpsk_ctx *c, const float *h)
     if (!c || !h) return fail(QPSK_ERR_ARG, "null argument");
     if (bind(c)) return QPSK_ERR_HIP;
     memcpy(c->taps, h, sizeof c->taps);
+    c->fast_valid = false;
     return upload_config(c);
 }
 
@@ -748,6 +752,26 @@ int qpsk_rrc_fir_batch(qpsk_ctx *c, float *d_memory, const float *d_in, float *d
     }
     KERNEL_TRY(launch_rrc_fir(src, d_memory, d_out, c->d_taps, nframes, length, c->stream));
     if (d_memory) KERNEL_TRY(launch_delay_line(src, d_memory, nframes, length, c->stream));
+    return QPSK_OK;
+}
+
+int qpsk_rrc_fir_batch_fast(qpsk_ctx *c, float *d_memory, const float *d_in, float *d_out, int nframes, int length)
+{
+    if (!c || !d_in || !d_out) return fail(QPSK_ERR_ARG, "qpsk_rrc_fir_batch_fast: null argument");
+    if (nframes <= 0 || length <= 0) return fail(QPSK_ERR_ARG, "qpsk_rrc_fir_batch_fast: nframes %d length %d", nframes, length);
+    if (d_in == d_out) return fail(QPSK_ERR_ARG, "qpsk_rrc_fir_batch_fast: every block reads 126 samples in front of it: separate buffers");
+    if (bind(c)) return QPSK_ERR_HIP;
+    if (!c->fast_valid) {      /* the filter's spectrum and the twiddles, in double on the host (host_math.c) */
+        const int n = rrc_fir_fast_nfft();
+        std::vector<float> t(4 * (size_t)n);
+        qpsk_host_fir_fast_tables(c->taps, t.data(), t.data() + 2 * n);
+        if (!c->d_fast) HIP_TRY(hipMalloc((void **)&c->d_fast, sizeof(float) * t.size()));
+        HIP_TRY(hipStreamSynchronize(c->stream));      /* an earlier call may still read the old tables */
+        HIP_TRY(hipMemcpy(c->d_fast, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice));
+        c->fast_valid = true;
+    }
+    KERNEL_TRY(launch_rrc_fir_fast(d_in, d_memory, d_out, c->d_fast, c->d_fast + 2 * rrc_fir_fast_nfft(), nframes, length, c->stream));
+    if (d_memory) KERNEL_TRY(launch_delay_line(d_in, d_memory, nframes, length, c->stream));
     return QPSK_OK;
 }
 

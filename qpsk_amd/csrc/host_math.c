@@ -125,6 +125,27 @@ void qpsk_host_scramble_keystream(unsigned char *ks, int nsym)
     }
 }
 
+void qpsk_host_fir_fast_tables(const float taps[QPSK_HOST_NTAPS], float *H, float *tw)
+{
+    const int n = 512;
+    for (int m = 0; m < n; m++) {
+        const double a = 2.0 * PI_D * (double)m / (double)n;
+        tw[2 * m] = (float)cos(a);
+        tw[2 * m + 1] = (float)-sin(a);
+    }
+    for (int k = 0; k < n; k++) {
+        double re = 0.0, im = 0.0;
+        for (int i = 0; i < QPSK_HOST_NTAPS; i++) {          /* h[i] = taps[126 - i]: memory[126] is the newest sample */
+            const double a = 2.0 * PI_D * (double)((i * k) % n) / (double)n;
+            const double h = (double)taps[QPSK_HOST_NTAPS - 1 - i];
+            re += h * cos(a);
+            im -= h * sin(a);
+        }
+        H[2 * k] = (float)(re * RRC_GAIN / (double)n);       /* GAIN again on taps that already sum to GAIN (rrc_fir.c:28, 73-74) */
+        H[2 * k + 1] = (float)(im * RRC_GAIN / (double)n);
+    }
+}
+
 void qpsk_host_twiddles(int n, double *tw)
 {
     for (int m = 0; m < n / 2; m++) {

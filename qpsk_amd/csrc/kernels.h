@@ -82,6 +82,11 @@ int launch_rx_lean(const FusedArgs &a, int G, unsigned long long layout, int *st
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s);
 int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s);
+/* firfast.hip: overlap-save FIR, 512-point fp32 FFTs (not a parity path); H, tw: [512][2] floats from qpsk_host_fir_fast_tables */
+int launch_rrc_fir_fast(const float *x, const float *memory, float *y, const float *H, const float *tw, int nframes, int length,
+                        hipStream_t s);
+int rrc_fir_fast_hop(void);
+int rrc_fir_fast_nfft(void);
 int launch_timing_hist(const float *y, int nframes, int frame_size, int cycles, int32_t *index, int32_t *hist,
                        bool generic, hipStream_t s);   /* generic: always the any-CYCLES scan (test knob) */
 int launch_costas(const float *d, int nframes, int nsym, int dstride, int nbw, const float *gains, float min_freq,

@@ -1405,7 +1405,7 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
     constexpr int WS = lean::WS;
     float2 *dring = reinterpret_cast<float2 *>(rows);
     float *zring = reinterpret_cast<float *>(rows + lean::Z_OFFSET_BYTES);
-    const int L = a.frame_size, N = a.nsym;
+    const int N = a.nsym;
     const int fl = lane / QL, q = lane % QL;
     const bool simd0 = (hwave & 3) == 0;                 /* placed beside the serial wave (layout): keeps priority 3 */
     unsigned *prm = reinterpret_cast<unsigned *>(rows + (size_t)hwave * lean::ROW_BYTES + lean::Z_OFFSET_BYTES);

@@ -38,6 +38,7 @@ QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so txt power_ablations python3 tools/powe
 txt pitch_sweep python3 tools/pitch_sweep.py --frames 8192
 QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so txt pitch_sweep_floor python3 tools/pitch_sweep.py --frames 8192 --dbg 49153
 [ -x build_ubench/ubench_fetch ] && txt ubench_fetch build_ubench/ubench_fetch
+txt fir_fast python3 tools/bench_fir_fast.py
 txt dropin python3 tools/bench_dropin.py 2000
 txt config5 python3 tools/bench_config5.py
 ls $O/*.failed 2>/dev/null
