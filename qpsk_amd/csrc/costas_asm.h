@@ -335,6 +335,11 @@ __device__ __forceinline__ void costas_asm_run_ring(float &phase, float &freq, u
         "ds_read_b128 v[120:123], v132\n\t"
         "s_mov_b64 %[fl], 0\n\t"
         "s_waitcnt lgkmcnt(0)\n"
+        /* the group loop's head 12 bytes behind a 64-byte boundary: a lone wave is limited by instruction fetch (header), and where
+         * the 8-byte instructions of the 16-step body fall relative to the 32-byte fetch lines is worth 4 % -- 157.2 cycles
+         * per step at this offset, 160.9 as the compiler placed it, 163.4 at the worst (tools/ubench_step.py --align,
+         * profiles/r03_step_cost.txt; re-measure after any edit of the stream) */
+        ".p2align 6\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n"
         "2:\n\t"
         /* ring addresses of group k and of group k + 1's first pair; the producer counter */
         "s_and_b32 %[t0], %[k], 7\n\t"

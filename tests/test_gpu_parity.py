@@ -348,8 +348,8 @@ def test_full_size_config2_histogram_timing(oracle):
 
 
 def test_full_size_config4_shard_properties(oracle):
-    """BASELINE config 4's per-GPU share (8192 frames x 16384 samples, 1 GiB), which rx_pipe2_kernel takes as 256
-    workgroups of 32 frames: (a) a spread sample of frames equals the oracle bit for bit, (b) the 16-frame workgroups
+    """BASELINE config 4's per-GPU share (8192 frames x 16384 samples, 1 GiB), which rx_lean_kernel takes as 256
+    workgroups of 32 frames (ten FIR waves, 160 KB of LDS): (a) a spread sample of frames equals the oracle bit for bit, (b) the 16-frame workgroups
     of rx_fused_pipe_kernel (two rounds) give the same bits everywhere, (c) every loop ends on the +50 Hz offset."""
     import torch
     import bench
@@ -358,16 +358,18 @@ def test_full_size_config4_shard_properties(oracle):
     x = bench.synth_frames_gpu(torch, torch.device("cuda", 0), F, m.taps, seed=11)
     a = m.rx_batch(x)
     m.sync()
+    assert m.last_kernel() == "rx_lean_kernel"
     pick = np.unique(np.concatenate([np.arange(0, F, 211), [1, 31, 32, 33, F - 33, F - 32, F - 1]]))
     want = oracle.rx_batch(x[torch.from_numpy(pick).cuda()].cpu().numpy(), fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED,
                            fixed_index=bench.FIXED_INDEX)
     for k in ("sym", "phase", "freq", "hz"):
         assert bits_equal(cpu(a[k])[pick], want[k]), k
-    m.tune(pipe_v=1)
-    b = m.rx_batch(x)
-    m.sync()
-    for k in ("sym", "phase", "freq"):
-        assert bits_equal(cpu(a[k]), cpu(b[k])), k
+    for v in (1, 2):     # rx_fused_pipe_kernel in two rounds, rx_pipe2_kernel: the same bits everywhere
+        m.tune(pipe_v=v)
+        b = m.rx_batch(x)
+        m.sync()
+        for k in ("sym", "phase", "freq"):
+            assert bits_equal(cpu(a[k]), cpu(b[k])), (k, v)
     assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
 
 

@@ -30,10 +30,11 @@ def no_branch(s):
 
 
 def no_fillers(s):
-    """the head without the previous step's leftovers (clamp, zero test) and without the wrap test: FIN must then be
-    v118 itself -- timing only, the arithmetic is no longer the loop's"""
+    """the head without the previous step's leftovers (clamp in place, zero test) and without the wrap test -- timing only,
+    the arithmetic is no longer the loop's"""
     s = s.replace('"v_cmp_ge_f32_e64 vcc, |" PIN "|, %[tau]\\n\\t"', '')
-    s = s.replace('"v_med3_f32 " FIN ", v118, %[fmin], %[fmax]\\n\\t"', '"v_mov_b32 " FIN ", v118\\n\\t"')
+    assert '"v_med3_f32 v118, v118, %[fmin], %[fmax]\\n\\t"' in s
+    s = s.replace('"v_med3_f32 v118, v118, %[fmin], %[fmax]\\n\\t"', '')
     s = s.replace('"v_min3_f32 v126, v126, |v114|, |v115|\\n\\t"', '')
     return s
 
@@ -44,9 +45,11 @@ def no_sign(s):
 
 
 def aligned(pad):
-    """label 2 (the group loop's head) on a 64-byte boundary plus `pad` s_nops (4 bytes each) in costas_asm_run_ring"""
+    """label 2 (the group loop's head) on a 64-byte boundary plus `pad` s_nops (4 bytes each) in costas_asm_run_ring (the
+    shipped header has its own alignment line there: replaced)"""
     def f(s):
         i = s.index("costas_asm_run_ring(")
+        s = s[:i] + re.sub(r'"\.p2align 6\\n(\\ts_nop 0\\n)*"\n', '', s[i:], count=1)
         j = s.index('"2:\\n\\t"', i)
         return s[:j] + '".p2align 6\\n\\t' + "s_nop 0\\n\\t" * pad + '"\n        ' + s[j:]
     return f
@@ -54,7 +57,7 @@ def aligned(pad):
 
 VARIANTS = {
     "0_as_shipped": lambda s: s,
-    "a02_loop_head_aligned": aligned(2),
+    **{"a%02d_loop_head_aligned" % k: aligned(k) for k in ((0, 1, 2, 3, 4, 5, 6, 7, 9, 11, 13, 15) if "--align" in sys.argv else (2,))},
     "1_no_lds": no_lds,
     "2_no_wrap_branch": no_branch,
     "3_no_lds_no_branch": lambda s: no_branch(no_lds(s)),
