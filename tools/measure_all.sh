@@ -37,7 +37,8 @@ txt power_probe python3 tools/power_probe.py 4096 8192
 QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so txt power_ablations python3 tools/power_probe.py 8192 8192:1 8192:16384 8192:32768 8192:49153
 txt pitch_sweep python3 tools/pitch_sweep.py --frames 8192
 QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so txt pitch_sweep_floor python3 tools/pitch_sweep.py --frames 8192 --dbg 49153
-[ -x build_ubench/ubench_fetch ] && txt ubench_fetch build_ubench/ubench_fetch
+# micro-benchmarks are built on the box (build_ubench/ does not travel: .gpurunignore)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_fetch.hip -o /tmp/ubench_fetch > $O/ubench_fetch_build.log 2>&1 && txt ubench_fetch /tmp/ubench_fetch
 txt fir_fast python3 tools/bench_fir_fast.py
 txt dropin python3 tools/bench_dropin.py 2000
 txt config5 python3 tools/bench_config5.py

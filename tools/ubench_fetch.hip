@@ -2,7 +2,7 @@
 // One wave (alone on its CU) runs long straight-line blocks of the same operation in its 4-byte (e32), 8-byte (e64 / VOP3)
 // and 12-byte (VOP3 + literal... via v_add_f32 with a literal: 8 bytes in e32 form) encodings, dependent and independent,
 // then the same blocks with 1 or 2 partner waves on the same SIMD idle / busy.  Not product code.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_fetch.hip -o build_ubench/ubench_fetch && build_ubench/ubench_fetch
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench_fetch.hip -o /tmp/ubench_fetch && /tmp/ubench_fetch      (tools/measure_all.sh does)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Builds tools/ubench_step.hip against variants of qpsk_amd/csrc/costas_asm.h (text substitutions on a copy: the
-product header is not touched) -> build_ubench/step/<variant>.bin; run them on the GPU box with
-    for b in build_ubench/step/*.bin; do $b $(basename $b .bin); done
+product header is not touched) -> build_ubench/step/<variant>.bin; run them on the GPU box (this script there, hipcc is
+in the image: build_ubench/ is in .gpurunignore) with
+    python tools/ubench_step.py [--align] && for b in build_ubench/step/*.bin; do $b $(basename $b .bin); done
 What each variant removes from the serial wave's step tells what that piece costs the wave."""
 import os
 import re
