@@ -232,6 +232,15 @@ __device__ __forceinline__ void costas_step_t(float &phase, float &freq, float a
     freq = f;
 }
 
+/* a 16-byte load of data that is read ONCE (the input samples): nontemporal, i.e. not parked in the caches on its way --
+ * worth 1.5 % of rx_lean_kernel's time at the board's power limit */
+__device__ __forceinline__ float4 load_once(const float4 *p)
+{
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const v4f_ v = __builtin_nontemporal_load(reinterpret_cast<const v4f_ *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 /* NaN / Inf inputs are fenced, not reproduced: a non-finite sample reaches its loop through the filter and the loop state
  * then stays non-finite to the end of the frame (phase = phase + ...), where the kernel flags the call (STATUS_NONFINITE ->
  * QPSK_ERR_RANGE).  The reference itself spins forever in phase_wrap() on an infinite phase (costas_loop.c:61-67) and goes

@@ -682,7 +682,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
             for (int ff = 0; ff < FWV; ff++)
 #pragma unroll
                 for (int j = 0; j < NLD; j++)
-                    pre[ff][j] = cx.src[ff][(c * CH + 128 * j + 2 * lane) >> 1];
+                    pre[ff][j] = load_once(&cx.src[ff][(c * CH + 128 * j + 2 * lane) >> 1]);
         } else {
 #pragma unroll
             for (int ff = 0; ff < FWV; ff++) {
@@ -690,7 +690,7 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
                 for (int j = 0; j < NLD; j++) {
                     const int s = c * CH + 128 * j + 2 * lane;      /* first sample of the pair */
                     const bool in = cx.fv[ff] && s + 1 < L;
-                    float4 v = cx.src[ff][in ? (s >> 1) : 0];
+                    float4 v = load_once(&cx.src[ff][in ? (s >> 1) : 0]);
                     if (!in) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     pre[ff][j] = v;
                 }
@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
             for (int ff = 0; ff < UF; ff++)
 #pragma unroll
                 for (int j = 0; j < NLD; j++)
-                    pre[ff][j] = U.src[ff][(c * CH + 128 * j + 2 * lane) >> 1];
+                    pre[ff][j] = load_once(&U.src[ff][(c * CH + 128 * j + 2 * lane) >> 1]);
         } else {
 #pragma unroll
             for (int ff = 0; ff < UF; ff++)
@@ -1043,7 +1043,7 @@ __device__ __forceinline__ void fir_wave2(const FusedArgs &a, Smem *sm, float2 *
                 for (int j = 0; j < NLD; j++) {
                     const int s = c * CH + 128 * j + 2 * lane;
                     const bool in = U.fv[ff] && s + 1 < L;
-                    float4 v = U.src[ff][in ? (s >> 1) : 0];
+                    float4 v = load_once(&U.src[ff][in ? (s >> 1) : 0]);
                     if (!in) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     pre[ff][j] = v;
                 }
