@@ -172,7 +172,7 @@ timing_scan_kernel(const float2 *__restrict__ x, int nframes, int frame_size, co
         for (int ff = 0; ff < UF; ff++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                float4 v = src[ff][(t * TILE + 128 * j + 2 * lane) >> 1];
+                float4 v = load_once(&src[ff][(t * TILE + 128 * j + 2 * lane) >> 1]);      /* read once (qpsk_device.h) */
                 if (!fv[ff]) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 pre[ff][j] = v;
             }
