@@ -2,6 +2,7 @@
 """Measurement helper (GPU box): board power and shader clock (rocm-smi) while one receive-kernel shape runs back to back.
 
     python tools/power_probe.py [frames[:pipe_dbg[:key=val,key=val...]] ...]      (default: 4096 8192; keys as Modem.tune)
+    python tools/power_probe.py --cmd "<program and arguments>" ...                 (any GPU program running for ~6 s)
 A child process launches the kernel in a loop for ~6 s per shape; the parent samples rocm-smi once a second.
 With QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so (measurement build) the pipe_dbg bits 1 / 16384 / 32768 select rx_lean_kernel's
 streams without the filter arithmetic / the window reads / the flush arithmetic: their times at the power limit price the parts."""
@@ -50,7 +51,18 @@ def smi():
 
 
 print("idle:", smi(), flush=True)
-for arg in sys.argv[1:] or ["4096", "8192"]:
+args = sys.argv[1:]
+if args and args[0] == "--cmd":      # any program that prints a line when it has finished: python tools/power_probe.py --cmd "/tmp/ubench_valu 6 2" ...
+    for cmd in args[1:]:
+        p = subprocess.Popen(cmd.split(), stdout=subprocess.PIPE, text=True)
+        time.sleep(2.5)
+        for i in range(2):
+            print("%s, t+%ds: %s" % (cmd, i + 2, smi()), flush=True)
+            time.sleep(0.5)
+        print(p.stdout.read().strip(), flush=True)
+        p.wait()
+    sys.exit(0)
+for arg in args or ["4096", "8192"]:
     parts = arg.split(":")
     frames, dbg, tune = int(parts[0]), int(parts[1] or "0", 0) if len(parts) > 1 else 0, parts[2] if len(parts) > 2 else ""
     p = subprocess.Popen([sys.executable, "-c", CHILD, str(frames), "5", str(dbg), tune], stdout=subprocess.PIPE, text=True)
