@@ -326,7 +326,11 @@ def main():
         tr, src = traffic_of(F_)
         return {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "kernel_ms": kms,
-                "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * F_ * L}
+                "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * F_ * L,
+                # context, not a claim of this run: what a synthetic kernel with nothing but this path's operation mix (63.5
+                # unfused flops per 8 input bytes on random data + the window reads) sustains on this part before it throttles
+                "operation_mix_ceiling": {"input_gbs": [4500.0, 4800.0], "source": "profiles/r03_power_ceiling.txt "
+                                          "(tools/ubench_valu_power.hip under tools/power_probe.py, an earlier session)"}}
 
     import hashlib
     lib_file = qpsk_amd.lib_path()
