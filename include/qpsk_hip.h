@@ -151,7 +151,7 @@ int qpsk_rx_batch(qpsk_ctx *ctx, const float *d_in, int nframes, uint8_t *d_sym,
  * two frames are never read).  Why a caller would: with frames a power of two apart (16384 samples = 128 KB) every frame's
  * sample n sits in the same HBM channel group, and a batch kernel streams sample n of ALL its frames at about the same time --
  * measured on MI355X, the memory side then delivers 4.4 TB/s to this access pattern against 5.2 TB/s at a pitch of
- * frame_size + 512 samples.  QPSK_TIMING_FIXED only for a pitch other than frame_size. */
+ * frame_size + 512 samples.  Every timing mode. */
 int qpsk_rx_batch_pitched(qpsk_ctx *ctx, const float *d_in, long long frame_pitch, int nframes, uint8_t *d_sym,
                           float *d_freq, float *d_phase, float *d_costas, int32_t *d_index, float *d_hz);
 

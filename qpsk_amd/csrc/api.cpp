@@ -428,7 +428,7 @@ static int get_twiddles(qpsk_ctx *c, int n, double **out)
 }
 
 static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index, float *d_y = nullptr,
-                              double *d_X = nullptr)
+                              double *d_X = nullptr, size_t pitch = 0)
 {
     const int C = c->cycles, nfft = timing_fft_nfft();
     if (C < 2 || C > 8 || (C & (C - 1)))
@@ -450,7 +450,7 @@ static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32
     } else {
         cs = it->second;
     }
-    KERNEL_TRY(launch_timing_fft(d_in, nframes, c->prm.frame_size, C, c->d_taps, tw, cs, d_index, d_y, d_X, c->stream));
+    KERNEL_TRY(launch_timing_fft(d_in, nframes, c->prm.frame_size, C, c->d_taps, tw, cs, d_index, d_y, d_X, c->stream, pitch));
     return QPSK_OK;
 }
 
@@ -461,7 +461,7 @@ static bool scan_fused_ok(const qpsk_ctx *c, const float *d_in)
            tuned(c->tune.hist_generic, 0) == 0;
 }
 
-static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int32_t **d_index_out)
+static int timing_indices(qpsk_ctx *c, const float *d_in, size_t pitch, int nframes, const int32_t **d_index_out)
 {
     *d_index_out = nullptr;
     if (c->prm.timing_mode == QPSK_TIMING_FIXED) return QPSK_OK;
@@ -470,23 +470,23 @@ static int timing_indices(qpsk_ctx *c, const float *d_in, int nframes, const int
     if (c->prm.timing_mode == QPSK_TIMING_HIST) {
         /* the fused full-rate FIR + scan kernel keeps the filtered block in LDS (timing_scan.hip): the input is read
          * once here and once by the pipeline kernel that follows, nothing is written but the index */
-        if (scan_fused_ok(c, d_in)) {
+        if (scan_fused_ok(c, d_in) && (pitch & 1) == 0) {
             KERNEL_TRY(launch_timing_scan(d_in, nframes, c->prm.frame_size, c->d_taps, (int32_t *)c->index.p, nullptr,
-                                          c->d_status, c->stream));
+                                          c->d_status, c->stream, pitch));
             *d_index_out = (const int32_t *)c->index.p;
             return QPSK_OK;
         }
         const size_t bytes = sizeof(float) * 2 * (size_t)nframes * c->prm.frame_size;
         rc = ensure(c, c->filtered, bytes);
         if (rc) return rc;
-        KERNEL_TRY(launch_rrc_fir(d_in, nullptr, (float *)c->filtered.p, c->d_taps, nframes, c->prm.frame_size, c->stream));
+        KERNEL_TRY(launch_rrc_fir(d_in, nullptr, (float *)c->filtered.p, c->d_taps, nframes, c->prm.frame_size, c->stream, pitch));
         KERNEL_TRY(launch_timing_hist((const float *)c->filtered.p, nframes, c->prm.frame_size, c->cycles,
                                       (int32_t *)c->index.p, nullptr, tuned(c->tune.hist_generic, 0) == 2, c->stream));
         *d_index_out = (const int32_t *)c->index.p;
         return QPSK_OK;
     }
     /* QPSK_TIMING_FFT: symbol-rate line of |y|^2 through the reference's radix-2 FFT (timing_fft.hip) */
-    rc = fft_timing_indices(c, d_in, nframes, (int32_t *)c->index.p);
+    rc = fft_timing_indices(c, d_in, nframes, (int32_t *)c->index.p, nullptr, nullptr, pitch);
     if (rc) return rc;
     *d_index_out = (const int32_t *)c->index.p;
     return QPSK_OK;
@@ -500,11 +500,9 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     if (frame_pitch == 0) frame_pitch = c->prm.frame_size;
     if (frame_pitch < c->prm.frame_size)
         return fail(QPSK_ERR_ARG, "qpsk_rx_batch_pitched: frame_pitch %lld below frame_size %d", frame_pitch, c->prm.frame_size);
-    if (frame_pitch != c->prm.frame_size && c->prm.timing_mode != QPSK_TIMING_FIXED)
-        return fail(QPSK_ERR_ARG, "qpsk_rx_batch_pitched: a pitch other than frame_size needs QPSK_TIMING_FIXED (the timing estimators read packed frames)");
     if (bind(c)) return QPSK_ERR_HIP;
     const int32_t *idx = nullptr;
-    int rc = timing_indices(c, d_in, nframes, &idx);
+    int rc = timing_indices(c, d_in, (size_t)frame_pitch, nframes, &idx);
     if (rc) return rc;
 
     FusedArgs a{};

@@ -80,7 +80,7 @@ unsigned long long lean_default_layout(int NU);         /* rx_lean_kernel: 1, 5,
 bool lean_shape_ok(const FusedArgs &a, int G);          /* one loop per frame, whole chunks, whole even workgroups, ... */
 int launch_rx_lean(const FusedArgs &a, int G, unsigned long long layout, int *status, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
-                   hipStream_t s);
+                   hipStream_t s, size_t in_pitch = 0);      /* in_pitch: samples between input frames (0 = length) */
 int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s);
 /* firfast.hip: overlap-save FIR, 512-point fp32 FFTs (not a parity path); H, tw: [512][2] floats from qpsk_host_fir_fast_tables */
 int launch_rrc_fir_fast(const float *x, const float *memory, float *y, const float *H, const float *tw, int nframes, int length,
@@ -106,10 +106,10 @@ size_t timing_scan_lds_bytes(void);
 int timing_scan_tile(void);
 int prepare_timing_scan(void);
 int launch_timing_scan(const float *x, int nframes, int frame_size, const float *taps, int32_t *index, int32_t *hist,
-                       int *status, hipStream_t s);
+                       int *status, hipStream_t s, size_t pitch = 0);
 /* timing_fft.hip */
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
-                      const double *cs, int32_t *index, float *yout, double *Xout, hipStream_t s);   /* yout [nframes][512][2],
+                      const double *cs, int32_t *index, float *yout, double *Xout, hipStream_t s, size_t pitch = 0);   /* yout [nframes][512][2],
                       Xout [nframes][512][2] optional: the estimator's filtered samples and spectrum, for the parity tests */
 int timing_fft_nfft(void);
 int timing_fft_first(void);

@@ -191,7 +191,7 @@ constexpr int FIR_SLOTS = FIR_WIN + FIR_WIN / 8 + 1;
 
 __global__ void __launch_bounds__(FIR_THREADS, 2)
 rrc_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ memory, float2 *__restrict__ y,
-               const float *__restrict__ taps_g, int length)
+               const float *__restrict__ taps_g, int length, size_t in_pitch)
 {
     __shared__ __attribute__((aligned(16))) float taps[128];
     __shared__ float2 xs[FIR_SLOTS];
@@ -203,7 +203,7 @@ rrc_fir_kernel(const float2 *__restrict__ x, const float2 *__restrict__ memory, 
         const int n = n0 - HIST + i;
         float2 v = make_float2(0.0f, 0.0f);
         if (n >= 0) {
-            if (n < length) v = x[(size_t)f * length + n];
+            if (n < length) v = x[(size_t)f * in_pitch + n];       /* input frames in_pitch samples apart, output packed */
         } else if (memory) {
             v = memory[(size_t)f * NTAPS + (NTAPS + n)]; /* n = -1 -> memory[126] */
         }
@@ -739,11 +739,12 @@ int prepare_kernels(void)
 }
 
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
-                   hipStream_t s)
+                   hipStream_t s, size_t in_pitch)
 {
     dim3 grid((length + FIR_TILE - 1) / FIR_TILE, nframes);
     hipLaunchKernelGGL(rrc_fir_kernel, grid, dim3(FIR_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
-                       reinterpret_cast<const float2 *>(memory), reinterpret_cast<float2 *>(y), taps, length);
+                       reinterpret_cast<const float2 *>(memory), reinterpret_cast<float2 *>(y), taps, length,
+                       in_pitch ? in_pitch : (size_t)length);
     LAUNCH_CHECK();
     return 0;
 }

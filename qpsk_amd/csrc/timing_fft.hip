@@ -34,7 +34,7 @@ constexpr int TF_THREADS = 256;
 
 __global__ void __launch_bounds__(TF_THREADS)
 timing_fft_kernel(const float2 *__restrict__ x, int nframes, int frame_size, int cycles, const float *__restrict__ taps_g,
-                  const double2 *__restrict__ tw, const double2 *__restrict__ cs, int32_t *index, float2 *yout, double2 *Xout)
+                  const double2 *__restrict__ tw, const double2 *__restrict__ cs, int32_t *index, float2 *yout, double2 *Xout, size_t pitch)
 {
     __shared__ float taps[128];
     __shared__ float2 xs[TF_NFFT + HIST];
@@ -43,7 +43,7 @@ timing_fft_kernel(const float2 *__restrict__ x, int nframes, int frame_size, int
     if (tid < 128) taps[tid] = tid < NTAPS ? taps_g[tid] : 0.0f;
     for (int i = tid; i < TF_NFFT + HIST; i += TF_THREADS) {
         const int n = TF_N0 - HIST + i;              /* >= 2 */
-        xs[i] = n < frame_size ? x[(size_t)f * frame_size + n] : make_float2(0.0f, 0.0f);
+        xs[i] = n < frame_size ? x[(size_t)f * pitch + n] : make_float2(0.0f, 0.0f);
     }
     __syncthreads();
     constexpr int LOG2N = 9;
@@ -79,12 +79,12 @@ timing_fft_kernel(const float2 *__restrict__ x, int nframes, int frame_size, int
 }
 
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
-                      const double *cs, int32_t *index, float *yout, double *Xout, hipStream_t s)
+                      const double *cs, int32_t *index, float *yout, double *Xout, hipStream_t s, size_t pitch)
 {
     hipLaunchKernelGGL(timing_fft_kernel, dim3(nframes), dim3(TF_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
                        nframes, frame_size, cycles, taps, reinterpret_cast<const double2 *>(tw),
                        reinterpret_cast<const double2 *>(cs), index, reinterpret_cast<float2 *>(yout),
-                       reinterpret_cast<double2 *>(Xout));
+                       reinterpret_cast<double2 *>(Xout), pitch ? pitch : (size_t)frame_size);
     return (int)hipGetLastError();
 }
 

@@ -83,7 +83,7 @@ __device__ __forceinline__ void publish(int *p, int v)
 
 __global__ void __launch_bounds__(tscan::THREADS)
 timing_scan_kernel(const float2 *__restrict__ x, int nframes, int frame_size, const float *__restrict__ taps_g,
-                   int32_t *index, int32_t *hist_out, int *status)
+                   int32_t *index, int32_t *hist_out, int *status, size_t pitch)
 {
     using namespace tscan;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -157,7 +157,7 @@ timing_scan_kernel(const float2 *__restrict__ x, int nframes, int frame_size, co
     const float4 *src[UF];
 #pragma unroll
     for (int ff = 0; ff < UF; ff++)
-        src[ff] = reinterpret_cast<const float4 *>(x + (size_t)(fv[ff] ? f0 + UF * w + ff : 0) * frame_size);
+        src[ff] = reinterpret_cast<const float4 *>(x + (size_t)(fv[ff] ? f0 + UF * w + ff : 0) * pitch);      /* frames pitch samples apart */
     float2 *mywin = win + (size_t)(UF * w) * WSF;
     const unsigned rd_addr = lds_addr(mywin + fl * WSF + (R + PADS) * q);   /* position 8q -> slot 10q */
     const unsigned tap_addr = lds_addr(sm->taps);
@@ -265,12 +265,13 @@ int prepare_timing_scan(void)
 
 /* frame_size % 256 == 0, CYCLES = 8, x 16-byte aligned (host-checked) */
 int launch_timing_scan(const float *x, int nframes, int frame_size, const float *taps, int32_t *index, int32_t *hist,
-                       int *status, hipStream_t s)
+                       int *status, hipStream_t s, size_t pitch)
 {
     using namespace tscan;
-    if (frame_size % TILE != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return (int)hipErrorInvalidValue;
+    if (pitch == 0) pitch = (size_t)frame_size;
+    if (frame_size % TILE != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (pitch & 1)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(timing_scan_kernel, dim3((nframes + G - 1) / G), dim3(THREADS), timing_scan_lds_bytes(), s,
-                       reinterpret_cast<const float2 *>(x), nframes, frame_size, taps, index, hist, status);
+                       reinterpret_cast<const float2 *>(x), nframes, frame_size, taps, index, hist, status, pitch);
     return (int)hipGetLastError();
 }
 

@@ -1046,8 +1046,7 @@ def test_nonfinite_input_is_an_error(oracle, kernel, bad):
 @pytest.mark.parametrize("kernel,L,F,extra", [("pipe", 1024, 40, 64), ("lean", 1024, 512, 512), ("lean", 2048, 96, 34), ("generic", 1000, 9, 2)])
 def test_pitched_frames(oracle, kernel, L, F, extra):
     """qpsk_rx_batch_pitched: frames frame_size + extra samples apart (the gap filled with NaN: never read) give the packed
-    call's bits on every receive kernel; a pitch below frame_size, an odd pitch on the pipeline kernels' path and a pitch
-    with an estimating timing mode are refused."""
+    call's bits on every receive kernel and in every timing mode; a pitch below frame_size is refused."""
     import torch
     import qpsk_amd
     fs, rs = 19200.0, 2400.0
@@ -1070,9 +1069,19 @@ def test_pitched_frames(oracle, kernel, L, F, extra):
     assert_batch_equal(dict(sym=sym, freq=fr, phase=ph), want, keys=("sym", "phase", "freq"))
     with pytest.raises(qpsk_amd.QpskError, match="frame_pitch"):
         m.rx_batch_raw(buf, F, sym, fr, ph, pitch=L - 2)
-    mh = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_HIST)
-    with pytest.raises(qpsk_amd.QpskError, match="QPSK_TIMING_FIXED"):
-        mh.rx_batch_raw(buf, F, sym, fr, ph, pitch=L + extra)
+    # the estimating timing modes read the same pitched frames (fused scan kernel where the shape allows, else rrc_fir + scan; FFT)
+    from oracle.pyoracle import TIMING_FFT
+    for mode in (TIMING_HIST, TIMING_FFT) if cyc == 8 else (TIMING_HIST,):
+        if mode == TIMING_FFT and L < 1024:
+            continue
+        mt = modem(fs=fs, rs=rs, frame_size=L, timing_mode=mode)
+        if kernel == "lean":
+            mt.tune(pipe_v=3)
+        n = min(F, 64)
+        wt = oracle.rx_batch(x[:n], fs, rs, loop_bw=BW, timing_mode=mode)
+        mt.rx_batch_raw(buf, n, sym, fr, ph, pitch=L + extra)
+        mt.sync()
+        assert_batch_equal(dict(sym=sym[:n], freq=fr[:n], phase=ph[:n]), wt, keys=("sym", "phase", "freq"))
 
 
 def test_caller_stream_ordering_contract(oracle):
