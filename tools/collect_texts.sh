@@ -32,12 +32,14 @@ echo "reads after the first two blocks, 32768: no flush arithmetic, 49153: all t
 echo
 grep -v "amdgpu.ids\|^idle" $O/power_ablations.log
 echo
+[ -s $O/r3_power_c2.log ] && { echo "Config 2 (rx_fused_pipe_kernel), measurement build: QPSK_PIPE_DBG 1 = no filter arithmetic, 2 = no recurrence, 3 = neither:"; echo; cat $O/r3_power_c2.log; echo; }
 echo "Reading.  Both shapes run AT the board's power limit (1400 W): 8192 frames at 1.86-1.93 GHz, config 2 at 1360-1395 W and 2.25-2.30 GHz"
 echo "(the part's maximum is 2.40 GHz).  Without the filter's arithmetic the same kernel draws 1190-1210 W at 2.395 GHz and takes 0.243-0.247 ms: that is"
 echo "the memory side's floor for this access pattern at a 128 KB frame pitch (${tag}_pitch_sweep.txt), 7-9 % under the full kernel."
 echo "With the clock set by power, cycles saved buy little time (the 1, 5, 5, 5 layout: -14.5 % cycles per chunk round, -4 to -6 % time);"
 echo "what a part costs in TIME is what it costs in energy: the flush 3.5-4 %, the filter's LDS reads 2-4 %, not parking the once-read input in the"
-echo "caches (nontemporal loads) 1.5 %, the filter arithmetic the rest above the floor."
+echo "caches (nontemporal loads) 1.5 %, the filter arithmetic the rest above the floor.  Config 2 sits where its two limits meet: the recurrence alone"
+echo "(no filter arithmetic: 966 W, 2.39 GHz) takes 0.144 ms, the filter side alone (no recurrence, still at the limit: 1364 W) 0.152 ms, both 0.157."
 } > $P/${tag}_power.txt
 {
 echo "qpsk_rx_batch_pitched on the bench signal, 8192 frames, frames (16384 + extra) samples apart, interleaved in one process (tools/pitch_sweep.py)."
