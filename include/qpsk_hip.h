@@ -198,6 +198,13 @@ int qpsk_timing_scan_batch(qpsk_ctx *ctx, const float *d_in, int nframes, int32_
 int qpsk_timing_fft_batch(qpsk_ctx *ctx, const float *d_in, int nframes, int32_t *d_index, float *d_filtered,
                           double *d_spectrum);
 
+/* The same estimate by the kernel qpsk_rx_batch() runs in QPSK_TIMING_FFT mode: of the 512-point transform only the
+ * butterflies the symbol-rate bin X[512 / CYCLES] depends on are evaluated (511 of the recursion's fft.c:55-63 steps,
+ * each with the full transform's operands, twiddle and order).
+ *   d_bin  [nframes] complex double, may be NULL: that bin -- bit for bit d_spectrum[f][512 / CYCLES] above. */
+int qpsk_timing_fft_bin_batch(qpsk_ctx *ctx, const float *d_in, int nframes, int32_t *d_index, float *d_filtered,
+                              double *d_bin);
+
 /* Costas loop + slicer (qpsk.c:196-212) over already decimated symbols.
  *   d_symbols_in [nframes][nsym] complex float;  d_state [nframes][2] float (phase, freq) in/out,
  *   NULL = start from (0,0) and do not write back. */

@@ -428,7 +428,7 @@ static int get_twiddles(qpsk_ctx *c, int n, double **out)
 }
 
 static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index, float *d_y = nullptr,
-                              double *d_X = nullptr, size_t pitch = 0)
+                              double *d_X = nullptr, size_t pitch = 0, double *d_bin = nullptr)
 {
     const int C = c->cycles, nfft = timing_fft_nfft();
     if (C < 2 || C > 8 || (C & (C - 1)))
@@ -450,7 +450,7 @@ static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32
     } else {
         cs = it->second;
     }
-    KERNEL_TRY(launch_timing_fft(d_in, nframes, c->prm.frame_size, C, c->d_taps, tw, cs, d_index, d_y, d_X, c->stream, pitch));
+    KERNEL_TRY(launch_timing_fft(d_in, nframes, c->prm.frame_size, C, c->d_taps, tw, cs, d_index, d_y, d_X, d_bin, c->stream, pitch, c->ncu));
     return QPSK_OK;
 }
 
@@ -801,6 +801,14 @@ int qpsk_timing_fft_batch(qpsk_ctx *c, const float *d_in, int nframes, int32_t *
     if (nframes <= 0) return fail(QPSK_ERR_ARG, "nframes = %d", nframes);
     if (bind(c)) return QPSK_ERR_HIP;
     return fft_timing_indices(c, d_in, nframes, d_index, d_filtered, d_spectrum);
+}
+
+int qpsk_timing_fft_bin_batch(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index, float *d_filtered, double *d_bin)
+{
+    if (!c || !d_in || !d_index) return fail(QPSK_ERR_ARG, "qpsk_timing_fft_bin_batch: null argument");
+    if (nframes <= 0) return fail(QPSK_ERR_ARG, "nframes = %d", nframes);
+    if (bind(c)) return QPSK_ERR_HIP;
+    return fft_timing_indices(c, d_in, nframes, d_index, d_filtered, nullptr, 0, d_bin);
 }
 
 int qpsk_costas_batch(qpsk_ctx *c, const float *d_symbols_in, int nframes, int nsym, float *d_state, uint8_t *d_sym,

@@ -109,8 +109,10 @@ int launch_timing_scan(const float *x, int nframes, int frame_size, const float 
                        int *status, hipStream_t s, size_t pitch = 0);
 /* timing_fft.hip */
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
-                      const double *cs, int32_t *index, float *yout, double *Xout, hipStream_t s, size_t pitch = 0);   /* yout [nframes][512][2],
-                      Xout [nframes][512][2] optional: the estimator's filtered samples and spectrum, for the parity tests */
+                      const double *cs, int32_t *index, float *yout, double *Xout, double *Xk, hipStream_t s, size_t pitch = 0,
+                      int ncu = 0);   /* optional, for the parity tests: yout [nframes][512][2] the estimator's filtered samples,
+                      Xout [nframes][512][2] the whole spectrum (selects the variant that runs the full transform beside the
+                      pruned one), Xk [nframes][2] the symbol-rate bin as the pruned transform delivers it */
 int timing_fft_nfft(void);
 int timing_fft_first(void);
 /* bitstages.hip */

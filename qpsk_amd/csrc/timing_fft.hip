@@ -3,10 +3,9 @@
  * reference's radix-2 FFT (algorithms/fft.c:38-120).
  *
  * NEW DESIGN: the reference has no FFT timing estimator (fft.c is never called);
- * BASELINE.json config 3 asks for one.  What is pinned to the reference is the transform itself (the
- * butterflies, twiddles and 1/N scaling of fft.c, shared with fft_kernel through fft_lds.h); the estimator
- * on top is checked against the CPU oracle's restatement of THIS definition (parity unpinned by the
- * reference):
+ * BASELINE.json config 3 asks for one.  What is pinned to the reference is the filter (rrc_fir.c:17-30) and the
+ * transform itself (the butterflies, twiddles and 1/N scaling of fft.c); the estimator on top is checked against
+ * the CPU oracle's restatement of THIS definition (parity unpinned by the reference):
  *
  *   y[n]   = rrc_fir() output of the frame (fresh delay line), n = 128 .. 128+NFFT-1   (rrc_fir.c:17-30)
  *   p[m]   = (double)y.re^2 + (double)y.im^2                      (two products, one sum, unfused, fp64)
@@ -16,79 +15,242 @@
  *   index  = first i with the largest c_i      = Re(X_k e^{+j 2 pi i / CYCLES}): the offset whose
  *            symbol-spaced samples carry the most energy.
  *
- * One workgroup per frame: 638 input samples staged in LDS, 512 FIR outputs (taps 0..126 in order, one
- * fp32 accumulator: the same numbers rrc_fir_kernel produces), transform in LDS, one int32 out.
+ * Round 4: ONE WAVE PER FRAME, everything hand-placed for a 64-wide wavefront.
+ *   - the 638 input samples of a frame (x[2..639]) go from five coalesced 16-byte loads per lane (the next frame's
+ *     are in flight while this one is filtered) into the wave's LDS window in the image fir_full8_asm.h reads
+ *     (position p at slot p + 2 (p / 8): lanes 80 bytes apart, pairs are aligned 16-byte words);
+ *   - the 512 filter outputs are ONE pass of the generated full-rate stream (fir_full8_asm.h: lane l owns outputs
+ *     8l .. 8l+7, 1016 packed multiplies + 1016 packed adds, taps 0..126 in order, one fp32 accumulator per output --
+ *     the instruction stream timing_scan_kernel runs, the same numbers rrc_fir_kernel produces);
+ *   - only bin k = NFFT/CYCLES of the transform is wanted, so only the butterflies it depends on are evaluated:
+ *     the reference's recursion (fft.c:38-64) needs, of a sub-transform of size m, the single bin k mod m -- 256 + 128
+ *     + ... + 1 = 511 butterfly halves instead of 2304 whole butterflies, each with the operands, the twiddle
+ *     (fft.c:55-56) and the operation order (fft.c:57-63) of the full transform: X_k is bit-identical to fftn()'s.
+ *     Level s (size m = 2^s) pairs element id with id + 512/m: after one transposition through LDS (lane l takes
+ *     p[l + 64 j], j < 8) levels 1-3 are inside a lane and levels 4-9 are lane l with lane l + 32, 16, ... 1.
+ * FULL = true additionally runs the whole transform in LDS (the butterflies of fft_lds.h, one wave per frame) and
+ * returns the spectrum: what the parity tests compare with fft_kernel, and the pruned bin with it.
  * The cos/sin tables (twiddles, candidate phases) are built on the host with libm like the reference's.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "qpsk_device.h"
-#include "fft_lds.h"
+#include "costas_asm.h"      /* lds_addr() */
+#include "fir_full8_asm.h"
 #include "kernels.h"
 
 namespace qpsk {
 
-constexpr int TF_N0 = 128;      /* first output used: the delay line is primed after 126 samples; multiple of CYCLES */
-constexpr int TF_NFFT = 512;    /* NFFT of fft.h:44 */
-constexpr int TF_THREADS = 256;
+namespace tfft {
+constexpr int N0 = 128;        /* first output used: the delay line is primed after 126 samples; multiple of CYCLES */
+constexpr int NFFT = 512;      /* NFFT of fft.h:44 */
+constexpr int LOG2N = 9;
+constexpr int R = 8, PADS = 2; /* fir_full8_asm.h: 8 consecutive outputs per lane, window position p at slot p + 2 (p / 8) */
+constexpr int WPOS = NFFT + HIST;          /* 638 window positions: position p = sample p + N0 - HIST */
+constexpr int WSLOTS = 808;                /* float2 slots per wave: the stream's last (unused) pair read ends at slot 798 */
+constexpr int MAX_FPW = 4;                 /* frames a wave takes one after the other */
+__device__ __host__ constexpr int slot_of(int p) { return p + PADS * (p / R); }
+static_assert(slot_of(R * 63) + slot_of(NTAPS + R - 1 + 1) + 2 <= WSLOTS, "window: every slot the stream reads exists");
+static_assert(NFFT == 64 * R && slot_of(WPOS - 1) < WSLOTS && (NFFT + NFFT / 8) * sizeof(double) <= WSLOTS * sizeof(float2), "one pass of the stream per frame; p[] fits the window");
+static_assert(FIR_FULL8_ASM_END_VGPR <= 168, "up to three waves per SIMD");
 
-__global__ void __launch_bounds__(TF_THREADS)
-timing_fft_kernel(const float2 *__restrict__ x, int nframes, int frame_size, int cycles, const float *__restrict__ taps_g,
-                  const double2 *__restrict__ tw, const double2 *__restrict__ cs, int32_t *index, float2 *yout, double2 *Xout, size_t pitch)
+struct cd { double x, y; };
+
+/* one output of the butterfly of fft.c:55-63: e + w o (sg = +1: the node's bin k < m/2) or e - w o (sg = -1) */
+__device__ __forceinline__ cd half_butterfly(cd e, cd o, double wr, double wi, double sg)
 {
-    __shared__ float taps[128];
-    __shared__ float2 xs[TF_NFFT + HIST];
-    __shared__ __attribute__((aligned(16))) double2 v[TF_NFFT];
-    const int tid = threadIdx.x, f = blockIdx.x;
+    const double zr = wr * o.x - wi * o.y;      /* fft.c:57 */
+    const double zi = wr * o.y + wi * o.x;      /* fft.c:58 */
+    cd r;
+    r.x = e.x + sg * zr;                        /* fft.c:60-63; a - b and a + (-b) are the same operation */
+    r.y = e.y + sg * zi;
+    return r;
+}
+
+/* LDS is shared by the lanes of ONE wave here and a wave's LDS instructions execute in order: this only keeps the
+ * compiler from moving them across */
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+} // namespace tfft
+
+template <bool FULL, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+timing_fft_kernel(const float2 *__restrict__ x, int nframes, int fpw, int cycles, const float *__restrict__ taps_g,
+                  const double2 *__restrict__ tw, const double2 *__restrict__ cs, int32_t *index, float2 *yout, double2 *Xout,
+                  double2 *Xk, size_t pitch, int aligned)
+{
+    using namespace tfft;
+    __shared__ __attribute__((aligned(16))) float taps[128];
+    __shared__ __attribute__((aligned(16))) float2 wins[WAVES][WSLOTS];
+    __shared__ __attribute__((aligned(16))) double2 vfull[FULL ? WAVES : 1][FULL ? NFFT : 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < 128) taps[tid] = tid < NTAPS ? taps_g[tid] : 0.0f;
-    for (int i = tid; i < TF_NFFT + HIST; i += TF_THREADS) {
-        const int n = TF_N0 - HIST + i;              /* >= 2 */
-        xs[i] = n < frame_size ? x[(size_t)f * pitch + n] : make_float2(0.0f, 0.0f);
-    }
-    __syncthreads();
-    constexpr int LOG2N = 9;
-    for (int o = tid; o < TF_NFFT; o += TF_THREADS) {
-        float2 y = make_float2(0.0f, 0.0f);
-        for (int k = 0; k < NTAPS; k++)
-            fir_mac(y, xs[o + k], taps[k]);
-        y = fir_gain(y);
-        if (yout) yout[(size_t)f * TF_NFFT + o] = y;          /* the estimator's view of rrc_fir(): tests compare it with rrc_fir_kernel */
-        const double pr = (double)y.x * (double)y.x, pi = (double)y.y * (double)y.y;
-        const int r = (int)(__brev((unsigned)o) >> (32 - LOG2N));
-        v[r] = make_double2(pr + pi, 0.0);
-    }
-    __syncthreads();
-    fft_lds_stages(v, tw, TF_NFFT, LOG2N, tid, TF_THREADS, -1.0);
-    if (Xout) {                                               /* the whole spectrum as fftn() returns it (fft.c:117-119): tests compare it with fft_kernel */
-        __syncthreads();
-        for (int o = tid; o < TF_NFFT; o += TF_THREADS)
-            Xout[(size_t)f * TF_NFFT + o] = make_double2(v[o].x / (double)TF_NFFT, v[o].y / (double)TF_NFFT);
-    }
-    if (tid == 0) {
-        const double dn = (double)TF_NFFT;
-        const double2 raw = v[TF_NFFT / cycles];
-        const double xr = raw.x / dn, xi = raw.y / dn;       /* fft.c:117-119 */
-        int best = 0;
-        double hmax = xr * cs[0].x - xi * cs[0].y;
-        for (int i = 1; i < cycles; i++) {
-            const double c = xr * cs[i].x - xi * cs[i].y;
-            if (c > hmax) { hmax = c; best = i; }
+    __syncthreads();      /* the only workgroup barrier: from here on a wave works on its own */
+
+    float2 *win = wins[wave];
+    const unsigned rd_addr = lds_addr(win + (R + PADS) * lane);      /* position 8 lane -> slot 10 lane */
+    const unsigned tap_addr = lds_addr(taps);
+    const int k0 = NFFT / cycles;                                    /* the symbol-rate bin */
+    const int fbase = (blockIdx.x * WAVES + wave) * fpw;             /* this wave's frames: fbase .. fbase + fpw - 1 */
+
+    /* samples N0 - HIST .. N0 + NFFT - 1 = 2 .. 639 as pairs: pair i (samples 2i, 2i+1), i = 1 .. 319, lane l takes 1 + l + 64 j */
+    float4 pre[5];
+    auto prefetch = [&](int f) {
+        const float2 *src = x + (size_t)f * pitch;
+        if (aligned) {
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll
+            for (int j = 0; j < 5; j++) pre[j] = s4[min(1 + lane + 64 * j, (N0 + NFFT) / 2 - 1)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const int i = min(1 + lane + 64 * j, (N0 + NFFT) / 2 - 1);
+                const float2 a = src[2 * i], b = src[2 * i + 1];
+                pre[j] = make_float4(a.x, a.y, b.x, b.y);
+            }
         }
-        index[f] = best;
+    };
+    if (fbase < nframes) prefetch(fbase);
+    for (int it = 0; it < fpw; it++) {
+        const int f = fbase + it;
+        if (f >= nframes) break;
+        /* window from registers: pair i sits at positions 2 (i - 1), 2 (i - 1) + 1 -- one aligned 16-byte word of the image */
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int p = 2 * (lane + 64 * j);
+            if (j < 4 || lane < 63) *reinterpret_cast<float4 *>(win + slot_of(p)) = pre[j];
+        }
+        if (it + 1 < fpw && f + 1 < nframes) prefetch(f + 1);
+        wave_sync();
+        v2f a0, a1, a2, a3, a4, a5, a6, a7;
+        fir_full8_asm(rd_addr, tap_addr, a0, a1, a2, a3, a4, a5, a6, a7);      /* ends with every LDS read returned */
+        const v2f acc[R] = {a0, a1, a2, a3, a4, a5, a6, a7};
+        double pv[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float2 y = fir_gain(make_float2(acc[r].x, acc[r].y));          /* rrc_fir.c:28 */
+            if (yout) yout[(size_t)f * NFFT + R * lane + r] = y;                   /* the estimator's view of rrc_fir(): tests compare it with rrc_fir_kernel */
+            const double pr = (double)y.x * (double)y.x, pi = (double)y.y * (double)y.y;
+            pv[r] = pr + pi;
+        }
+        /* transposition through the window's LDS (the stream has finished with it): element o at double slot o + o/8 */
+        double *tp = reinterpret_cast<double *>(win);
+#pragma unroll
+        for (int r = 0; r < R; r++) tp[(R + 1) * lane + r] = pv[r];
+        if (FULL) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int o = R * lane + r;
+                vfull[FULL ? wave : 0][__brev((unsigned)o) >> (32 - LOG2N)] = make_double2(pv[r], 0.0);   /* fft.c:99-101 + the recursion's even/odd order */
+            }
+        }
+        wave_sync();
+        cd v[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int o = lane + 64 * j;
+            v[j].x = tp[o + (o >> 3)];
+            v[j].y = 0.0;
+        }
+        wave_sync();      /* the next frame's staging overwrites tp[] */
+        /* level s: nodes of size m = 2^s, the bin each must deliver is kb = k0 mod m: its twiddle index kb mod m/2 in a size-m
+         * transform = entry (kb mod m/2) * (NFFT / m) of the size-NFFT table (bit-identical: scaling an angle by a power of two is exact) */
+        auto level = [&](int s, double &wr, double &wi, double &sg) {
+            const int m = 1 << s, kb = k0 & (m - 1), kk = kb & (m / 2 - 1);
+            const double2 w = tw[kk << (LOG2N - s)];
+            wr = w.x;
+            wi = -1.0 * w.y;                   /* forward: w = cos - j sin (fft.c:55-56) */
+            sg = kb >= m / 2 ? -1.0 : 1.0;
+        };
+        double wr, wi, sg;
+        level(1, wr, wi, sg);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = half_butterfly(v[j], v[j + 4], wr, wi, sg);      /* id, id + 256 */
+        level(2, wr, wi, sg);
+#pragma unroll
+        for (int j = 0; j < 2; j++) v[j] = half_butterfly(v[j], v[j + 2], wr, wi, sg);      /* id, id + 128 */
+        level(3, wr, wi, sg);
+        cd u = half_butterfly(v[0], v[1], wr, wi, sg);                                       /* id, id + 64: id = lane */
+#pragma unroll
+        for (int s = 4; s <= LOG2N; s++) {
+            const int delta = 32 >> (s - 4);                                                 /* id, id + 512 / 2^s */
+            cd o;
+            o.x = __shfl_down(u.x, delta);
+            o.y = __shfl_down(u.y, delta);
+            level(s, wr, wi, sg);
+            u = half_butterfly(u, o, wr, wi, sg);
+        }
+        if (lane == 0) {
+            const double dn = (double)NFFT;
+            const double xr = u.x / dn, xi = u.y / dn;       /* fft.c:117-119 */
+            if (Xk) Xk[f] = make_double2(xr, xi);
+            int best = 0;
+            double hmax = xr * cs[0].x - xi * cs[0].y;
+            for (int i = 1; i < cycles; i++) {
+                const double c = xr * cs[i].x - xi * cs[i].y;
+                if (c > hmax) { hmax = c; best = i; }
+            }
+            index[f] = best;
+        }
+        if (FULL) {      /* the whole spectrum as fftn() returns it: fft_lds.h's stages with the wave as the workgroup */
+            double2 *vv = vfull[FULL ? wave : 0];
+            for (int s = 1; s <= LOG2N; s++) {
+                const int half = 1 << (s - 1), stride = NFFT >> s;
+                for (int b = lane; b < NFFT / 2; b += 64) {
+                    const int k = b & (half - 1);
+                    const int lo = ((b >> (s - 1)) << s) + k, hi = lo + half;
+                    const double2 w = tw[k * stride];
+                    const double wr_ = w.x, wi_ = -1.0 * w.y;
+                    const double2 e = vv[lo], o = vv[hi];
+                    const double zr = wr_ * o.x - wi_ * o.y;
+                    const double zi = wr_ * o.y + wi_ * o.x;
+                    vv[lo] = make_double2(e.x + zr, e.y + zi);
+                    vv[hi] = make_double2(e.x - zr, e.y - zi);
+                }
+                wave_sync();
+            }
+            if (Xout)
+                for (int o = lane; o < NFFT; o += 64)
+                    Xout[(size_t)f * NFFT + o] = make_double2(vv[o].x / (double)NFFT, vv[o].y / (double)NFFT);
+            wave_sync();
+        }
     }
 }
 
+/* ncu: compute units of the device (one workgroup of 8 waves per CU when the batch allows it) */
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
-                      const double *cs, int32_t *index, float *yout, double *Xout, hipStream_t s, size_t pitch)
+                      const double *cs, int32_t *index, float *yout, double *Xout, double *Xk, hipStream_t s, size_t pitch, int ncu)
 {
-    hipLaunchKernelGGL(timing_fft_kernel, dim3(nframes), dim3(TF_THREADS), 0, s, reinterpret_cast<const float2 *>(x),
-                       nframes, frame_size, cycles, taps, reinterpret_cast<const double2 *>(tw),
-                       reinterpret_cast<const double2 *>(cs), index, reinterpret_cast<float2 *>(yout),
-                       reinterpret_cast<double2 *>(Xout), pitch ? pitch : (size_t)frame_size);
+    using namespace tfft;
+    if (pitch == 0) pitch = (size_t)frame_size;
+    if (frame_size < N0 + NFFT) return (int)hipErrorInvalidValue;
+    const int aligned = (reinterpret_cast<uintptr_t>(x) % 16) == 0 && (pitch % 2) == 0;
+    const float2 *x2 = reinterpret_cast<const float2 *>(x);
+    const double2 *tw2 = reinterpret_cast<const double2 *>(tw), *cs2 = reinterpret_cast<const double2 *>(cs);
+    if (Xout) {
+        constexpr int WV = 4;
+        hipLaunchKernelGGL((timing_fft_kernel<true, WV>), dim3((nframes + WV - 1) / WV), dim3(64 * WV), 0, s, x2, nframes, 1, cycles,
+                           taps, tw2, cs2, index, reinterpret_cast<float2 *>(yout), reinterpret_cast<double2 *>(Xout),
+                           reinterpret_cast<double2 *>(Xk), pitch, aligned);
+    } else {
+        constexpr int WV = 8;
+        if (ncu < 1) ncu = 256;
+        int fpw = (nframes + ncu * WV - 1) / (ncu * WV);
+        if (fpw < 1) fpw = 1;
+        if (fpw > MAX_FPW) fpw = MAX_FPW;
+        const int per_wg = WV * fpw;
+        hipLaunchKernelGGL((timing_fft_kernel<false, WV>), dim3((nframes + per_wg - 1) / per_wg), dim3(64 * WV), 0, s, x2, nframes, fpw,
+                           cycles, taps, tw2, cs2, index, reinterpret_cast<float2 *>(yout), nullptr, reinterpret_cast<double2 *>(Xk),
+                           pitch, aligned);
+    }
     return (int)hipGetLastError();
 }
 
-int timing_fft_nfft(void) { return TF_NFFT; }
-int timing_fft_first(void) { return TF_N0; }
+int timing_fft_nfft(void) { return tfft::NFFT; }
+int timing_fft_first(void) { return tfft::N0; }
 
 } // namespace qpsk

@@ -47,7 +47,7 @@ API_SYMBOLS = [
     "qpsk_ctx_destroy", "qpsk_ctx_sync", "qpsk_ctx_set_stream", "qpsk_ctx_set_tuning", "qpsk_ctx_cycles", "qpsk_ctx_nsym",
     "qpsk_ctx_last_kernel",
     "qpsk_ctx_get_taps", "qpsk_ctx_get_gains", "qpsk_ctx_set_taps", "qpsk_ctx_set_loop", "qpsk_rx_batch", "qpsk_rx_batch_pitched",
-    "qpsk_rx_batch_bw", "qpsk_rrc_fir_batch", "qpsk_rrc_fir_batch_fast", "qpsk_timing_hist_batch", "qpsk_timing_scan_batch", "qpsk_timing_fft_batch", "qpsk_costas_batch", "qpsk_fft_batch",
+    "qpsk_rx_batch_bw", "qpsk_rrc_fir_batch", "qpsk_rrc_fir_batch_fast", "qpsk_timing_hist_batch", "qpsk_timing_scan_batch", "qpsk_timing_fft_batch", "qpsk_timing_fft_bin_batch", "qpsk_costas_batch", "qpsk_fft_batch",
     "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
     "qpsk_streams_rx_pcm", "qpsk_streams_rx_pcm_host", "qpsk_dev_alloc", "qpsk_dev_free", "qpsk_dev_upload", "qpsk_dev_download",
     "qpsk_selftest_sincos_hash", "qpsk_crc16_batch", "qpsk_interleave_batch", "qpsk_scramble_batch",
@@ -107,6 +107,7 @@ def load():
     L.qpsk_rrc_fir_batch_fast.argtypes = [vp, vp, vp, vp, i32, i32]
     L.qpsk_timing_hist_batch.argtypes = [vp, vp, i32, vp, vp]
     L.qpsk_timing_fft_batch.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.qpsk_timing_fft_bin_batch.argtypes = [vp, vp, i32, vp, vp, vp]
     L.qpsk_timing_scan_batch.argtypes = [vp, vp, i32, vp, vp]
     L.qpsk_costas_batch.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     L.qpsk_fft_batch.argtypes = [vp, vp, vp, i32, i32, i32]
@@ -300,6 +301,17 @@ class Modem:
         X = self.empty((F, 512), t.complex128) if want_internals else None
         self._check(self.L.qpsk_timing_fft_batch(self.h, _ptr(x), F, _ptr(idx), _ptr(y), _ptr(X)))
         return (idx, y, X) if want_internals else idx
+
+    def timing_fft_bin(self, frames):
+        """the estimate as qpsk_rx_batch runs it (pruned transform) -> index (F,), filtered (F, 512, 2), bin (F,) complex128"""
+        t = self.torch
+        x = self._dev(frames, t.float32)
+        F = x.shape[0]
+        idx = self.empty((F,), t.int32)
+        y = self.empty((F, 512, 2), t.float32)
+        xk = self.empty((F,), t.complex128)
+        self._check(self.L.qpsk_timing_fft_bin_batch(self.h, _ptr(x), F, _ptr(idx), _ptr(y), _ptr(xk)))
+        return idx, y, xk
 
     def costas(self, d, state=None, want_costas=True):
         t = self.torch

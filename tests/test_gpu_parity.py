@@ -1135,6 +1135,39 @@ def test_fft_timing_internals_are_the_pinned_stages(oracle):
     assert np.array_equal(cpu(idx), np.argmax(cand, axis=1))   # the rule itself (first maximum)
     want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FFT)
     assert np.array_equal(cpu(idx), want["index"])
+    # the kernel qpsk_rx_batch runs evaluates only the butterflies that bin depends on: same filter outputs, and the bin is
+    # the full transform's bit for bit
+    idx2, y2, xk = m.timing_fft_bin(x)
+    m.sync()
+    assert bits_equal(cpu(y2), cpu(y)) and bits_equal(cpu(xk), Xh) and np.array_equal(cpu(idx2), cpu(idx))
+
+
+@pytest.mark.parametrize("fs,F", [(19200.0, 5000), (9600.0, 2300), (4800.0, 2049)])
+def test_fft_timing_pruned_bin_many_frames(oracle, fs, F):
+    """more frames than one wave per frame of a full grid (a wave then takes several, one after the other, the next one's
+    samples in flight), a ragged last workgroup, CYCLES = 8, 4, 2 (bins 64, 128, 256), arbitrary (non-modem) samples, an input
+    that is not 16-byte aligned: the pruned bin equals the full transform's, the index the oracle's"""
+    import torch
+    from oracle.pyoracle import TIMING_FFT
+    rs, L = 2400.0, 640
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT)
+    if m.cycles == 2:      # rrc_make() (rrc_fir.c:32-76) yields NaN taps at two samples per symbol: the estimator is exercised on other taps
+        m.set_taps(modem(fs=19200.0, rs=rs, frame_size=L).taps)
+    x = random_frames(F, L, seed=int(fs))
+    idx, y, X = m.timing_fft(x, want_internals=True)
+    idx2, y2, xk = m.timing_fft_bin(x)
+    m.sync()
+    assert bits_equal(cpu(y2), cpu(y)) and bits_equal(cpu(xk), cpu(X)[:, 512 // m.cycles]) and np.array_equal(cpu(idx2), cpu(idx))
+    pick = np.unique(np.concatenate([np.arange(0, F, 97), [1, F - 1]]))
+    taps = m.taps
+    for f in pick:
+        assert int(cpu(idx2)[f]) == oracle.timing_fft_index(taps, x[f], m.cycles), f
+    # unaligned input (frames start 8 bytes off a 16-byte boundary)
+    buf = torch.zeros((F * L + 1, 2), dtype=torch.float32, device="cuda")
+    buf[1:] = torch.from_numpy(x).cuda().reshape(-1, 2)
+    idx3, y3, xk3 = m.timing_fft_bin(buf[1:].reshape(F, L, 2))
+    m.sync()
+    assert bits_equal(cpu(xk3), cpu(xk)) and np.array_equal(cpu(idx3), cpu(idx2))
 
 
 def test_full_size_config3_properties(oracle):
