@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-shard", action="store_true",
                     help="N = 1, config 2 only: skip the extra measurement of the 8192-frame per-GPU share (key shard_8192)")
+    ap.add_argument("--no-timing-modes", action="store_true",
+                    help="N = 1, config 2 only: skip the extra measurements of the same batch with the FFT timing estimate in front "
+                         "(BASELINE configs[2], key config3) and with the reference's histogram estimate (key hist)")
     ap.add_argument("--settle", type=float, default=0.25, help="seconds of untimed launches before the warmup steps (GPU clocks)")
     ap.add_argument("--frame-size", type=int, default=L, help="complex samples per frame (config 2: 16384)")
     args = ap.parse_args()
@@ -228,8 +231,8 @@ def main():
         if dist:
             dist.barrier()
 
-    def make_batch(F, seed):
-        m_ = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX,
+    def make_batch(F, seed, mode=qpsk_amd.TIMING_FIXED):
+        m_ = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=mode, fixed_index=FIXED_INDEX,
                             device=local)
         x_ = synth_frames_gpu(torch, dev, F, m_.taps, seed=seed)
         torch.cuda.synchronize()
@@ -373,6 +376,40 @@ def main():
         if ncpu > 0:
             xh = x[:ncpu].cpu().numpy()
             res["cpu_baseline"] = cpu_baseline(xh, m.taps)
+    if world == 1 and (F, L) == (FRAMES_1GPU, 16384) and not args.no_timing_modes:
+        # The same resident batch with a timing ESTIMATE in front of the receive kernel, by the same timed-region code, after
+        # config 2's region: key config3 = BASELINE configs[2] (the FFT timing estimate: timing_fft_kernel + receive kernel per
+        # step), key hist = the reference's own histogram estimate (qpsk.c:127-180: timing_scan_kernel + receive kernel).  A step
+        # is one qpsk_rx_batch call = two launches; frac is the batch's algorithmic bytes (8 B per sample) over the step.
+        for key, mode, steps_ in (("config3", qpsk_amd.TIMING_FFT, args.steps), ("hist", qpsk_amd.TIMING_HIST, max(1, args.steps // 4))):
+            mt = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=mode, fixed_index=FIXED_INDEX, device=local)
+            outs_t = (torch.empty_like(sym), torch.empty_like(freq), torch.empty_like(phase))
+            idx_t = torch.full((F,), -1, dtype=torch.int32, device=dev)
+            dtt, kmst = timed_region(mt, x, F, outs_t, steps_, max(1, args.warmup // (args.steps // steps_)), args.settle)
+            mt.rx_batch_raw(x, F, *outs_t, index=idx_t)
+            mt.sync()
+            ent = {"workload": "config 2's batch, %s in front of the fused receive kernel" % (
+                       "FFT timing estimate (BASELINE configs[2]; rrc_fir() of 512 samples per frame + the symbol-rate bin of fft.c's transform)"
+                       if key == "config3" else "the reference's histogram timing estimate (qpsk.c:127-180: full-rate rrc_fir() + scan)"),
+                   "kernels": ["timing_fft_kernel" if key == "config3" else "timing_scan_kernel", mt.last_kernel()],
+                   "steps": steps_, "ms_per_step": dtt / steps_ * 1e3, "step_ms_events": kmst,
+                   "msamples_per_s": F * L * steps_ / dtt / 1e6,
+                   "frac_of_hbm_peak_on_8B_per_sample": BYTES_PER_SAMPLE * F * L / (kmst * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "index_histogram": [int(v) for v in torch.bincount(idx_t.clamp(min=0), minlength=CYCLES).tolist()]}
+            if key == "config3":   # every clean frame's FFT estimate is the eye centre (= config 2's fixed offset), so the batch must
+                                   # equal config 2's bit for bit; the reference's histogram index is an amplitude-bin number
+                ent["symbols_equal_config2"] = bool(torch.equal(outs_t[0], sym))
+                ent["freq_bits_equal_config2"] = bool(torch.equal(outs_t[1].view(torch.int32), freq.view(torch.int32)))
+            if not args.no_parity:
+                from oracle.pyoracle import Oracle, TIMING_FFT, TIMING_HIST
+                npar_t = 32
+                want_t = Oracle().rx_batch(x[:npar_t].cpu().numpy(), FS, RS, timing_mode=TIMING_FFT if key == "config3" else TIMING_HIST)
+                ent["parity_frames_checked"] = npar_t
+                ent["symbol_mismatches"] = int(np.sum(outs_t[0][:npar_t].cpu().numpy() != want_t["sym"]))
+                ent["index_mismatches"] = int(np.sum(idx_t[:npar_t].cpu().numpy() != want_t["index"]))
+            res[key] = ent
+            mt.close()
+            del outs_t, idx_t
     if world == 1 and (F, L) == (FRAMES_1GPU, 16384) and not args.no_shard:
         # BASELINE configs[3]'s per-GPU share (8192 x 16384: the shape of every rank of an N > 1 run, and the one where
         # the filter, not the recurrence, is the limit) measured in the same run, after config 2's region and by the

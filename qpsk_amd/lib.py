@@ -243,12 +243,13 @@ class Modem:
                                          _ptr(o.get("costas")), _ptr(o.get("index")), _ptr(o.get("hz"))))
         return o
 
-    def rx_batch_raw(self, x, F, sym, freq, phase, pitch=0):
-        """No allocation, no checks: the call bench.py times.  pitch: complex samples between frame starts (0 = packed)."""
+    def rx_batch_raw(self, x, F, sym, freq, phase, pitch=0, index=None):
+        """No allocation, no checks: the call bench.py times.  pitch: complex samples between frame starts (0 = packed);
+        index: optional (F,) int32 tensor receiving the timing indices."""
         if pitch:
-            rc = self.L.qpsk_rx_batch_pitched(self.h, _ptr(x), pitch, F, _ptr(sym), _ptr(freq), _ptr(phase), None, None, None)
+            rc = self.L.qpsk_rx_batch_pitched(self.h, _ptr(x), pitch, F, _ptr(sym), _ptr(freq), _ptr(phase), None, _ptr(index), None)
         else:
-            rc = self.L.qpsk_rx_batch(self.h, _ptr(x), F, _ptr(sym), _ptr(freq), _ptr(phase), None, None, None)
+            rc = self.L.qpsk_rx_batch(self.h, _ptr(x), F, _ptr(sym), _ptr(freq), _ptr(phase), None, _ptr(index), None)
         if rc:
             self._check(rc)
 
