@@ -66,6 +66,7 @@ struct Tuning {
     int layout_lo = -1, layout_hi = -1;               /* rx_pipe2_kernel: units per hardware wave, 4 bits each (waves 1-5 / 6-11) */
     int pipe_variant = -1;                            /* pipeline kernel: layout bits (kernels.h, FusedArgs::dbg) */
     int hist_generic = -1;                            /* histogram estimate: 1 = rrc_fir + scan kernels (no fused scan), 2 = those with the generic scan */
+    int fir_generic = -1;                             /* full-rate rrc_fir(): 1 = the compiler-scheduled rrc_fir_kernel also for symmetric taps */
 };
 
 static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
@@ -74,6 +75,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
     {"QPSK_PIPE_DBG", &Tuning::pipe_variant}, {"QPSK_HIST_GENERIC", &Tuning::hist_generic},
     {"QPSK_PIPE_V", &Tuning::pipe_v},         {"QPSK_PIPE_G", &Tuning::pipe_g},
     {"QPSK_PIPE_LAYOUT_LO", &Tuning::layout_lo}, {"QPSK_PIPE_LAYOUT_HI", &Tuning::layout_hi},
+    {"QPSK_FIR_GENERIC", &Tuning::fir_generic},
 };
 
 /* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
@@ -391,6 +393,15 @@ int qpsk_ctx_set_loop(qpsk_ctx *c, float alpha, float beta, float min_freq, floa
 /* ---------------------------------------------------------------- tiling */
 static int tuned(int v, int dflt) { return v >= 0 ? v : dflt; }
 
+/* full-rate rrc_fir() of a batch of delay lines (rrc_fir.c:17-30): the generated stream with the taps in SGPRs when the
+ * filter is symmetric (firstream.hip), the compiler-scheduled kernel for any other tap set (kernels.hip) */
+static int fir_full_rate(qpsk_ctx *c, const float *x, const float *memory, float *y, int nframes, int length, size_t in_pitch = 0)
+{
+    if (c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0)
+        return launch_rrc_fir_stream(x, memory, y, c->d_taps, nframes, length, c->stream, in_pitch, c->ncu);
+    return launch_rrc_fir(x, memory, y, c->d_taps, nframes, length, c->stream, in_pitch);
+}
+
 /* frames per workgroup G and symbols per chunk S of rx_fused_kernel */
 static void pick_tiling(const qpsk_ctx *c, int nframes, int nbw, int *G, int *S)
 {
@@ -479,7 +490,7 @@ static int timing_indices(qpsk_ctx *c, const float *d_in, size_t pitch, int nfra
         const size_t bytes = sizeof(float) * 2 * (size_t)nframes * c->prm.frame_size;
         rc = ensure(c, c->filtered, bytes);
         if (rc) return rc;
-        KERNEL_TRY(launch_rrc_fir(d_in, nullptr, (float *)c->filtered.p, c->d_taps, nframes, c->prm.frame_size, c->stream, pitch));
+        KERNEL_TRY(fir_full_rate(c, d_in, nullptr, (float *)c->filtered.p, nframes, c->prm.frame_size, pitch));
         KERNEL_TRY(launch_timing_hist((const float *)c->filtered.p, nframes, c->prm.frame_size, c->cycles,
                                       (int32_t *)c->index.p, nullptr, tuned(c->tune.hist_generic, 0) == 2, c->stream));
         *d_index_out = (const int32_t *)c->index.p;
@@ -748,7 +759,7 @@ int qpsk_rrc_fir_batch(qpsk_ctx *c, float *d_memory, const float *d_in, float *d
         HIP_TRY(hipMemcpyAsync(c->mixed.p, d_in, bytes, hipMemcpyDeviceToDevice, c->stream));
         src = (const float *)c->mixed.p;
     }
-    KERNEL_TRY(launch_rrc_fir(src, d_memory, d_out, c->d_taps, nframes, length, c->stream));
+    KERNEL_TRY(fir_full_rate(c, src, d_memory, d_out, nframes, length));
     if (d_memory) KERNEL_TRY(launch_delay_line(src, d_memory, nframes, length, c->stream));
     return QPSK_OK;
 }
@@ -918,7 +929,7 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
     float *filt = (float *)c->filtered.p;
     int32_t *idx = (int32_t *)c->index.p;
     /* qpsk.c:125 */
-    KERNEL_TRY(launch_rrc_fir(d_in, c->s_memory, filt, c->d_taps, n, L, c->stream));
+    KERNEL_TRY(fir_full_rate(c, d_in, c->s_memory, filt, n, L));
     KERNEL_TRY(launch_delay_line(d_in, c->s_memory, n, L, c->stream));
     /* qpsk.c:127-180 */
     if (c->prm.timing_mode == QPSK_TIMING_HIST)

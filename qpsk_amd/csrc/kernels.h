@@ -81,6 +81,9 @@ bool lean_shape_ok(const FusedArgs &a, int G);          /* one loop per frame, w
 int launch_rx_lean(const FusedArgs &a, int G, unsigned long long layout, int *status, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s, size_t in_pitch = 0);      /* in_pitch: samples between input frames (0 = length) */
+/* firstream.hip: the same filter as the generated stream fir_full8s_asm.h (SYMMETRIC taps only: the caller checks) */
+int launch_rrc_fir_stream(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
+                          hipStream_t s, size_t in_pitch = 0, int ncu = 0);
 int launch_delay_line(const float *x, float *memory, int nframes, int length, hipStream_t s);
 /* firfast.hip: overlap-save FIR, 512-point fp32 FFTs (not a parity path); H, tw: [512][2] floats from qpsk_host_fir_fast_tables */
 int launch_rrc_fir_fast(const float *x, const float *memory, float *y, const float *H, const float *tw, int nframes, int length,

@@ -496,11 +496,18 @@ def test_config5_long_frames_bandwidth_sweep(oracle):
 
 
 # ------------------------------------------------------------------ stages
-def test_rrc_fir_batch_with_delay_lines(oracle):
+@pytest.mark.parametrize("kernel", ["stream", "generic", "asymmetric"])
+def test_rrc_fir_batch_with_delay_lines(oracle, kernel):
+    """rrc_fir() on batches of delay lines: the generated stream with the taps in SGPRs (firstream.hip: symmetric filters), the
+    compiler-scheduled kernel (QPSK_FIR_GENERIC = 1), and a tap set that is NOT symmetric (always the latter)"""
     import torch
     m = modem(fs=19200.0, rs=2400.0, frame_size=1024)
     rng = np.random.default_rng(2)
-    for n in (1, 5, 126, 127, 128, 1000, 1024, 4097):
+    if kernel == "generic":
+        m.tune(fir_generic=1)
+    if kernel == "asymmetric":
+        m.set_taps(rng.standard_normal(127).astype(np.float32))
+    for n in (1, 5, 126, 127, 128, 511, 512, 513, 1000, 1024, 4097):
         F = 5
         x = rng.standard_normal((F, n, 2)).astype(np.float32)
         mem = rng.standard_normal((F, 127, 2)).astype(np.float32)
@@ -520,6 +527,22 @@ def test_rrc_fir_batch_with_delay_lines(oracle):
         ym, mm = x[f].copy(), np.zeros((127, 2), np.float32)
         oracle.rrc_fir(m.taps, mm, ym)
         assert bits_equal(cpu(y[f]), ym)
+    # one long delay line (cut into runs that re-read the 126 samples in front of them), many short ones, and input
+    # that does not start on a 16-byte boundary
+    for F, n in ((1, 70000), (2, 33333), (700, 640)):
+        x = rng.standard_normal((F, n, 2)).astype(np.float32)
+        mem = rng.standard_normal((F, 127, 2)).astype(np.float32)
+        buf = torch.zeros((F * n + 1, 2), dtype=torch.float32, device="cuda")
+        buf[1:] = torch.from_numpy(x).cuda().reshape(-1, 2)
+        for xin in (x, buf[1:].reshape(F, n, 2)):
+            d_mem = torch.from_numpy(mem.copy()).cuda()
+            y = m.rrc_fir(xin, d_mem)
+            m.sync()
+            for f in sorted(set((0, F // 2, F - 1))):
+                ym, mm = x[f].copy(), mem[f].copy()
+                oracle.rrc_fir(m.taps, mm, ym)
+                assert bits_equal(cpu(y[f]), ym), (F, n, f)
+                assert bits_equal(cpu(d_mem[f]), mm), (F, n, f)
 
 
 def _ulp_distance(a, b):
