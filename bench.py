@@ -62,6 +62,32 @@ def synth_frames_gpu(torch, dev, nframes, taps, seed, offset_hz=50.0):
     return out
 
 
+def tx_frames_gpu(torch, dev, qpsk_amd, nframes, seed, offset_hz=50.0, local=0):
+    """The same stimulus from the library's own transmit chain (qpsk.c:225-285): one transmitter per frame,
+    random dibits -> qpsk_tx_symbols() = Gray map, zero-stuffing and TX RRC shaping in tx_shape_kernel -> its complex baseband
+    output, rotated by the +50 Hz carrier offset the reference tests (qpsk.c:320 against 342).  N2 at the scale it was written
+    for: 1 GiB of frames per GPU built in place from 16 MB of symbols, nothing staged from the host.  Returns (F, L, 2) float32."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    nsym = L // CYCLES
+    mt = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX, device=local)
+    mt.tx_reset(nframes, 0.0)
+    sym = torch.randint(0, 4, (nframes, nsym), generator=g, device=dev, dtype=torch.uint8)
+    out = mt.tx_symbols(sym, want_pcm=False, want_baseband=True)["baseband"]
+    mt.sync()
+    mt.close()
+    n = torch.arange(L, device=dev, dtype=torch.float64)
+    ang = 2.0 * np.pi * offset_hz * n / FS
+    cr, ci = torch.cos(ang).float(), torch.sin(ang).float()
+    chunk = 512
+    for f0 in range(0, nframes, chunk):
+        f1 = min(nframes, f0 + chunk)
+        re, im = out[f0:f1, :, 0].clone(), out[f0:f1, :, 1].clone()
+        out[f0:f1, :, 0] = re * cr - im * ci
+        out[f0:f1, :, 1] = re * ci + im * cr
+    return out
+
+
 def cpu_baseline(x_host, taps):
     """The reference's CPU path timed on this box's host cores, on a bounded sample of the same frames.
     kind "reference": oracle/_ref (the untouched reference compiled with its own Makefile flags, one core,
@@ -182,6 +208,8 @@ def main():
     ap.add_argument("--no-timing-modes", action="store_true",
                     help="N = 1, config 2 only: skip the extra measurements of the same batch with the FFT timing estimate in front "
                          "(BASELINE configs[2], key config3) and with the reference's histogram estimate (key hist)")
+    ap.add_argument("--stimulus", choices=["tx", "synth"], default="tx",
+                    help="tx: frames from the library's own transmit chain (qpsk_tx_symbols, N2); synth: torch conv1d (rounds 1-3)")
     ap.add_argument("--settle", type=float, default=0.25, help="seconds of untimed launches before the warmup steps (GPU clocks)")
     ap.add_argument("--frame-size", type=int, default=L, help="complex samples per frame (config 2: 16384)")
     args = ap.parse_args()
@@ -234,7 +262,10 @@ def main():
     def make_batch(F, seed, mode=qpsk_amd.TIMING_FIXED):
         m_ = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=mode, fixed_index=FIXED_INDEX,
                             device=local)
-        x_ = synth_frames_gpu(torch, dev, F, m_.taps, seed=seed)
+        if args.stimulus == "tx":
+            x_ = tx_frames_gpu(torch, dev, qpsk_amd, F, seed=seed, local=local)
+        else:
+            x_ = synth_frames_gpu(torch, dev, F, m_.taps, seed=seed)
         torch.cuda.synchronize()
         return m_, x_, (torch.empty((F, m_.nsym), dtype=torch.uint8, device=dev),
                         torch.empty((F,), dtype=torch.float32, device=dev),
@@ -347,6 +378,8 @@ def main():
         "value": value, "unit": "Msamples/s", "n_gpus": ndistinct, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "clock_settle_s": args.settle,
+        "stimulus": ("library transmit chain: random dibits -> qpsk_tx_symbols (tx_shape_kernel: Gray map, zero-stuffing, TX RRC) -> +50 Hz rotation"
+                     if args.stimulus == "tx" else "torch: random dibits -> Gray map -> zero-stuffing -> conv1d with the RX taps -> +50 Hz rotation"),
         # n_gpus counts DISTINCT physical devices (host + PCI address of every rank, gathered); ranks that share a GPU
         # (a rehearsal of the launch path on a smaller box) show up as ranks > n_gpus and gpu_shared
         "ranks": joined, "gpu_shared": ndistinct < joined, "devices": idents,
@@ -391,7 +424,8 @@ def main():
             ent = {"workload": "config 2's batch, %s in front of the fused receive kernel" % (
                        "FFT timing estimate (BASELINE configs[2]; rrc_fir() of 512 samples per frame + the symbol-rate bin of fft.c's transform)"
                        if key == "config3" else "the reference's histogram timing estimate (qpsk.c:127-180: full-rate rrc_fir() + scan)"),
-                   "kernels": ["timing_fft_kernel" if key == "config3" else "timing_scan_kernel", mt.last_kernel()],
+                   "kernels": ([mt.last_kernel()] if "inside the launch" in mt.last_kernel() else
+                               ["timing_fft_kernel" if key == "config3" else "timing_scan_kernel", mt.last_kernel()]),
                    "steps": steps_, "ms_per_step": dtt / steps_ * 1e3, "step_ms_events": kmst,
                    "msamples_per_s": F * L * steps_ / dtt / 1e6,
                    "frac_of_hbm_peak_on_8B_per_sample": BYTES_PER_SAMPLE * F * L / (kmst * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -67,6 +67,7 @@ struct Tuning {
     int pipe_variant = -1;                            /* pipeline kernel: layout bits (kernels.h, FusedArgs::dbg) */
     int hist_generic = -1;                            /* histogram estimate: 1 = rrc_fir + scan kernels (no fused scan), 2 = those with the generic scan */
     int fir_generic = -1;                             /* full-rate rrc_fir(): 1 = the compiler-scheduled rrc_fir_kernel also for symmetric taps */
+    int fft_fused = -1;                               /* FFT timing estimate: 0 = always a launch of its own (1 / unset: inside rx_fused_pipe_kernel's launch for full workgroups) */
 };
 
 static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
@@ -75,7 +76,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
     {"QPSK_PIPE_DBG", &Tuning::pipe_variant}, {"QPSK_HIST_GENERIC", &Tuning::hist_generic},
     {"QPSK_PIPE_V", &Tuning::pipe_v},         {"QPSK_PIPE_G", &Tuning::pipe_g},
     {"QPSK_PIPE_LAYOUT_LO", &Tuning::layout_lo}, {"QPSK_PIPE_LAYOUT_HI", &Tuning::layout_hi},
-    {"QPSK_FIR_GENERIC", &Tuning::fir_generic},
+    {"QPSK_FIR_GENERIC", &Tuning::fir_generic}, {"QPSK_FFT_FUSED", &Tuning::fft_fused},
 };
 
 /* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
@@ -438,8 +439,8 @@ static int get_twiddles(qpsk_ctx *c, int n, double **out)
     return QPSK_OK;
 }
 
-static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index, float *d_y = nullptr,
-                              double *d_X = nullptr, size_t pitch = 0, double *d_bin = nullptr)
+/* the FFT timing estimate's host-built tables: size-512 twiddles and the CYCLES candidate phases (libm, like fft.c:55-56) */
+static int fft_timing_tables(qpsk_ctx *c, double **tw_out, double **cs_out)
 {
     const int C = c->cycles, nfft = timing_fft_nfft();
     if (C < 2 || C > 8 || (C & (C - 1)))
@@ -461,7 +462,19 @@ static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32
     } else {
         cs = it->second;
     }
-    KERNEL_TRY(launch_timing_fft(d_in, nframes, c->prm.frame_size, C, c->d_taps, tw, cs, d_index, d_y, d_X, d_bin, c->stream, pitch, c->ncu));
+    *tw_out = tw;
+    *cs_out = cs;
+    return QPSK_OK;
+}
+
+static int fft_timing_indices(qpsk_ctx *c, const float *d_in, int nframes, int32_t *d_index, float *d_y = nullptr,
+                              double *d_X = nullptr, size_t pitch = 0, double *d_bin = nullptr)
+{
+    double *tw = nullptr, *cs = nullptr;
+    int rc = fft_timing_tables(c, &tw, &cs);
+    if (rc) return rc;
+    KERNEL_TRY(launch_timing_fft(d_in, nframes, c->prm.frame_size, c->cycles, c->d_taps, tw, cs, d_index, d_y, d_X, d_bin, c->stream, pitch,
+                                 c->ncu, c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0));
     return QPSK_OK;
 }
 
@@ -472,12 +485,15 @@ static bool scan_fused_ok(const qpsk_ctx *c, const float *d_in)
            tuned(c->tune.hist_generic, 0) == 0;
 }
 
-static int timing_indices(qpsk_ctx *c, const float *d_in, size_t pitch, int nframes, const int32_t **d_index_out)
+/* fused_fft: the caller will run the FFT estimate inside the receive launch (rx_fused_pipe_kernel, full workgroups): no
+ * launch here, *d_index_out stays NULL; c->index is sized for the indices the kernel leaves */
+static int timing_indices(qpsk_ctx *c, const float *d_in, size_t pitch, int nframes, const int32_t **d_index_out, bool fused_fft = false)
 {
     *d_index_out = nullptr;
     if (c->prm.timing_mode == QPSK_TIMING_FIXED) return QPSK_OK;
     int rc = ensure(c, c->index, sizeof(int32_t) * (size_t)nframes);
     if (rc) return rc;
+    if (fused_fft && c->prm.timing_mode == QPSK_TIMING_FFT) return QPSK_OK;
     if (c->prm.timing_mode == QPSK_TIMING_HIST) {
         /* the fused full-rate FIR + scan kernel keeps the filtered block in LDS (timing_scan.hip): the input is read
          * once here and once by the pipeline kernel that follows, nothing is written but the index */
@@ -512,8 +528,31 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     if (frame_pitch < c->prm.frame_size)
         return fail(QPSK_ERR_ARG, "qpsk_rx_batch_pitched: frame_pitch %lld below frame_size %d", frame_pitch, c->prm.frame_size);
     if (bind(c)) return QPSK_ERR_HIP;
+    /* the pipeline kernel (rx_fused.hip) is built for CYCLES = 8, 16-byte aligned frames and an index
+     * below CYCLES; everything else takes the generic chunked kernel (kernels.hip) */
+    const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 && (frame_pitch % 2) == 0 &&
+                         ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames(1) <= 64 &&
+                         tuned(c->tune.generic, 0) == 0;
+    /* BASELINE config 3's shape -- FFT timing estimate, a batch that fills rx_fused_pipe_kernel's 16-frame workgroups -- runs the
+     * estimate inside the receive launch (rx_fused.hip); every other shape launches timing_fft_kernel in front.  The conditions
+     * restate which kernel and geometry the code below will pick. */
+    bool fused_fft = false;
+    double *est_tw = nullptr, *est_cs = nullptr;
+    if (c->prm.timing_mode == QPSK_TIMING_FFT && pipe_ok && nbw == 1 && tuned(c->tune.fft_fused, 1) != 0 &&
+        tuned(c->tune.pipe_v, nframes > 16 * c->ncu ? 2 : 1) == 1 && c->prm.frame_size >= timing_fft_first() + timing_fft_nfft() &&
+        !(tuned(c->tune.pipe_variant, 0) & (128 | 4))) {
+        const int full = pipe_max_nf();
+        int nf = 1;
+        while (nf < full && (long long)c->ncu * pipe_frames(nf) < nframes) nf++;
+        nf = tuned(c->tune.pipe_nf, nf);
+        if (nf >= full && pipe_lds_bytes(full, nbw) <= (size_t)MAX_LDS_BYTES) {
+            int rt = fft_timing_tables(c, &est_tw, &est_cs);
+            if (rt) return rt;
+            fused_fft = true;
+        }
+    }
     const int32_t *idx = nullptr;
-    int rc = timing_indices(c, d_in, (size_t)frame_pitch, nframes, &idx);
+    int rc = timing_indices(c, d_in, (size_t)frame_pitch, nframes, &idx, fused_fft);
     if (rc) return rc;
 
     FusedArgs a{};
@@ -526,6 +565,12 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     pick_tiling(c, nframes, nbw, &a.G, &a.S);
     a.index = idx;
     a.fixed_index = c->prm.fixed_index;
+    if (fused_fft) {
+        a.est_tw = reinterpret_cast<const double2 *>(est_tw);
+        a.est_cs = reinterpret_cast<const double2 *>(est_cs);
+        a.index_out = d_index ? (int32_t *)c->index.p : nullptr;
+        if (d_index) idx = (const int32_t *)c->index.p;      /* copied to the caller's array behind the launch, below */
+    }
     a.dbg = tuned(c->tune.pipe_variant, 0) & PIPE_VARIANT_MASK;
     a.taps = c->d_taps;
     a.gains = c->d_gains;
@@ -539,11 +584,6 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     a.costas = reinterpret_cast<float2 *>(d_costas);
     a.hz = d_hz;
     a.status = c->d_status;
-    /* the pipeline kernel (rx_fused.hip) is built for CYCLES = 8, 16-byte aligned frames and an index
-     * below CYCLES; everything else takes the generic chunked kernel (kernels.hip) */
-    const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 && (frame_pitch % 2) == 0 &&
-                         ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames(1) <= 64 &&
-                         tuned(c->tune.generic, 0) == 0;
     /* Two pipeline kernels [measured, DESIGN.md 4.1]: up to 16 frames per CU the recurrence is the limit and the
      * 16-frame workgroups of rx_fused_pipe_kernel (serial wave alone on its SIMD, four-symbol FIR lanes) are 2 %
      * ahead; above that the filter is the limit and rx_pipe2_kernel's 32-frame workgroups win by 20 % */
@@ -596,7 +636,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
             if (!fits(nf))
                 return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame", nf, nbw);
             KERNEL_TRY(launch_rx_fused_pipe(a, nf, c->d_status, c->stream));
-            c->last_kernel = "rx_fused_pipe_kernel";
+            c->last_kernel = a.est_tw ? "rx_fused_pipe_kernel (FFT timing estimate inside the launch)" : "rx_fused_pipe_kernel";
         } else {
             KERNEL_TRY(launch_rx_fused(a, c->stream));
             c->last_kernel = "rx_fused_kernel";

@@ -28,6 +28,12 @@ struct FusedArgs {
     int share_simd0;        /* rx_pipe2_kernel, set by its launcher: a FIR wave sits beside the serial wave (priorities, see there) */
     const int32_t *index;   /* [nframes] or NULL -> fixed_index */
     int fixed_index;
+    /* rx_fused_pipe_kernel, full 16-frame workgroups only (set by api.cpp when the shape allows it): the FFT timing estimate
+     * runs INSIDE the launch -- every hardware wave estimates two of the workgroup's frames before the pipeline starts
+     * (timing_fft_wave.h) -- instead of in a launch of its own in front.  est_tw: size-512 twiddle table, est_cs: the CYCLES
+     * candidate phases (both host-built, api.cpp); index_out [nframes] or NULL receives the indices.  NULL = off */
+    const double2 *est_tw, *est_cs;
+    int32_t *index_out;
     int dbg;                /* layout variants of the pipeline kernel, all bit-exact (qpsk_ctx_set_tuning "QPSK_PIPE_DBG"):
                                4 no spare waves, 8 C++ Costas step, 16 serial wave chunk by chunk (no stream across the ring hand-overs), 64 FIR waves that share a SIMD keep their hardware order (16-frame kernel), 128 one lane mapping for all FIR waves (the plain
                                layout).  Measurement build only (-DQPSK_PIPE_PROFILE; masked off by api.cpp otherwise):
@@ -113,7 +119,7 @@ int launch_timing_scan(const float *x, int nframes, int frame_size, const float 
 /* timing_fft.hip */
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
                       const double *cs, int32_t *index, float *yout, double *Xout, double *Xk, hipStream_t s, size_t pitch = 0,
-                      int ncu = 0);   /* optional, for the parity tests: yout [nframes][512][2] the estimator's filtered samples,
+                      int ncu = 0, bool symmetric = false);   /* optional, for the parity tests: yout [nframes][512][2] the estimator's filtered samples,
                       Xout [nframes][512][2] the whole spectrum (selects the variant that runs the full transform beside the
                       pruned one), Xk [nframes][2] the symbol-rate bin as the pruned transform delivers it */
 int timing_fft_nfft(void);

@@ -47,6 +47,8 @@
 #include "fir_r2_asm.h"
 #include "fir_r4_asm.h"
 #include "fir_lean_asm.h"      /* WS_LEAN_SLOTS, the streams */
+#include "fir_full8_asm.h"     /* the in-launch FFT timing estimate of rx_fused_pipe_kernel */
+#include "timing_fft_wave.h"
 #ifdef QPSK_PIPE_PROFILE
 #include "fir_lean_prof_asm.h"
 #endif
@@ -133,6 +135,7 @@ struct Smem {
     int consumed;             /* chunks consumed by the Costas wave */
     int abort_flag;
     int pad_[2];
+    int est_index[16];        /* rx_fused_pipe_kernel with the FFT timing estimate in the launch: the workgroup's decimation offsets */
 };
 
 __device__ __forceinline__ int ld_acquire(const int *p)
@@ -582,6 +585,39 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
     if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
     __syncthreads();      /* (no window to zero: a fresh delay line is a zero history in the FIR waves' registers) */
 
+    /* ---- BASELINE config 3: the FFT timing estimate inside the launch (timing_fft_wave.h; the host sets a.est_tw only for full
+     * 16-frame workgroups = 8 hardware waves).  Every hardware wave -- the serial wave and the two that retire included, all idle
+     * until the first chunk exists -- estimates frames 2 wave, 2 wave + 1 of the workgroup: 4 frames per SIMD, the full-rate
+     * stream fir_full8_asm.h on 512 samples each, its window in the (not yet used) frame windows' LDS.  No launch of its own, no
+     * drain and refill of the chip between the estimate and the pipeline; the indices never leave the CU. */
+    if (a.est_tw) {
+        float2 *ewin = win + (size_t)wave * tfft::WSLOTS;
+        const unsigned erd = lds_addr(ewin + (tfft::R + tfft::PADS) * lane), etap = lds_addr(sm->taps);
+        const int fe0 = f0 + 2 * wave;
+        /* both frames unconditionally (a frame past the batch's end re-reads the last one and its result is dropped): the samples
+         * stay in registers, the second frame's are in flight while the first is filtered */
+        const float2 *srcA = a.x + (size_t)min(fe0, a.nframes - 1) * a.frame_pitch;
+        const float2 *srcB = a.x + (size_t)min(fe0 + 1, a.nframes - 1) * a.frame_pitch;
+        tfft::Pre5 pre = tfft::load_frame5(srcA, lane);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            tfft::stage_frame5(ewin, lane, pre);
+            if (i == 0) pre = tfft::load_frame5(srcB, lane);
+            tfft::wave_sync();
+            v2f e0, e1, e2, e3, e4, e5, e6, e7;
+            fir_full8_asm(erd, etap, e0, e1, e2, e3, e4, e5, e6, e7);
+            const v2f eacc[tfft::R] = {e0, e1, e2, e3, e4, e5, e6, e7};
+            double epv[tfft::R];
+            const tfft::cd u = tfft::power_bin(eacc, ewin, lane, a.est_tw, tfft::NFFT / C, nullptr, epv);
+            if (lane == 0 && fe0 + i < a.nframes) {
+                const int best = tfft::pick_index(u, a.est_cs, C, nullptr);
+                sm->est_index[2 * wave + i] = best;
+                if (a.index_out) a.index_out[fe0 + i] = best;
+            }
+        }
+        __syncthreads();
+    }
+
     if (wave == 0) {
         costas_wave<GM>(a, sm, dring, zring, G, f0, lane, nchunks, status);
         return;
@@ -659,7 +695,8 @@ rx_fused_pipe_kernel(FusedArgs a, int *status)
         for (int ff = 0; ff < FWV; ff++) {
             const int fr = f0 + gbase + ff;
             cx.fv[ff] = fr < a.nframes;
-            const int ix = a.index ? (cx.fv[ff] ? a.index[fr] : 0) : a.fixed_index;   /* decimation offset, < C */
+            const int ix = a.est_tw ? (cx.fv[ff] ? sm->est_index[gbase + ff] : 0)
+                                    : a.index ? (cx.fv[ff] ? a.index[fr] : 0) : a.fixed_index;   /* decimation offset, < C */
             const int p0 = 2 * lane + 126 - ix;               /* window position of sample 2*lane of the chunk */
             cx.wr0[ff] = (gbase + ff) * WSLOTS + p0 + PADS * (p0 / PAD);
             cx.wr1[ff] = (gbase + ff) * WSLOTS + (p0 + 1) + PADS * ((p0 + 1) / PAD);
@@ -1623,6 +1660,10 @@ int launch_rx_fused_pipe(const FusedArgs &a0, int NF, int *status, hipStream_t s
     const int blocks = (a.nframes + G - 1) / G;
     const size_t lds = pipe_lds_bytes(NF, a.nbw);
     if (NF < 1 || NF > pipe_max_nf() || lds > (size_t)MAX_LDS_BYTES || G * a.nbw > 64) return (int)hipErrorInvalidValue;
+    /* the in-launch FFT timing estimate is written for the full workgroup: 8 hardware waves x 2 frames, windows in the frame windows' LDS */
+    if (a.est_tw && (a.mixed != 1 || !a.est_cs || a.frame_size < tfft::N0 + tfft::NFFT || a.index ||
+                     (size_t)8 * tfft::WSLOTS > (size_t)G * GeomNarrow::WSLOTS))
+        return (int)hipErrorInvalidValue;
     /* hardware waves of a workgroup with NF FIR waves: with spares, FIR wave k is hardware wave k + 1 + k/3 */
     const int nfir = a.mixed == 2 ? 2 * NF : NF;
     auto nwaves = [&](int spare) { return (spare && !(a.dbg & 4)) ? nfir + 1 + (nfir - 1) / 3 : nfir + 1; };

@@ -37,59 +37,33 @@
 #include "qpsk_device.h"
 #include "costas_asm.h"      /* lds_addr() */
 #include "fir_full8_asm.h"
+#include "fir_full8s_asm.h"
+#include "timing_fft_wave.h"
 #include "kernels.h"
 
 namespace qpsk {
 
-namespace tfft {
-constexpr int N0 = 128;        /* first output used: the delay line is primed after 126 samples; multiple of CYCLES */
-constexpr int NFFT = 512;      /* NFFT of fft.h:44 */
-constexpr int LOG2N = 9;
-constexpr int R = 8, PADS = 2; /* fir_full8_asm.h: 8 consecutive outputs per lane, window position p at slot p + 2 (p / 8) */
-constexpr int WPOS = NFFT + HIST;          /* 638 window positions: position p = sample p + N0 - HIST */
-constexpr int WSLOTS = 808;                /* float2 slots per wave: the stream's last (unused) pair read ends at slot 798 */
-constexpr int MAX_FPW = 4;                 /* frames a wave takes one after the other */
-__device__ __host__ constexpr int slot_of(int p) { return p + PADS * (p / R); }
-static_assert(slot_of(R * 63) + slot_of(NTAPS + R - 1 + 1) + 2 <= WSLOTS, "window: every slot the stream reads exists");
-static_assert(NFFT == 64 * R && slot_of(WPOS - 1) < WSLOTS && (NFFT + NFFT / 8) * sizeof(double) <= WSLOTS * sizeof(float2), "one pass of the stream per frame; p[] fits the window");
-static_assert(FIR_FULL8_ASM_END_VGPR <= 168, "up to three waves per SIMD");
+static_assert(FIR_FULL8_ASM_END_VGPR <= 168 && FIR_FULL8S_ASM_END_VGPR <= 104, "three / four waves per SIMD");
 
-struct cd { double x, y; };
-
-/* one output of the butterfly of fft.c:55-63: e + w o (sg = +1: the node's bin k < m/2) or e - w o (sg = -1) */
-__device__ __forceinline__ cd half_butterfly(cd e, cd o, double wr, double wi, double sg)
-{
-    const double zr = wr * o.x - wi * o.y;      /* fft.c:57 */
-    const double zi = wr * o.y + wi * o.x;      /* fft.c:58 */
-    cd r;
-    r.x = e.x + sg * zr;                        /* fft.c:60-63; a - b and a + (-b) are the same operation */
-    r.y = e.y + sg * zi;
-    return r;
-}
-
-/* LDS is shared by the lanes of ONE wave here and a wave's LDS instructions execute in order: this only keeps the
- * compiler from moving them across */
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-} // namespace tfft
-
-template <bool FULL, int WAVES>
+/* SYM: the filter is symmetric (host-checked) -- the stream with the taps in SGPRs (fir_full8s_asm.h: 104 VGPRs, so that
+ * sixteen waves = sixteen frames run on a CU at once, four per SIMD: 4.7 cycles per packed instruction and SIMD against 5.2
+ * with two waves, profiles/r03_power_ceiling.txt); otherwise the stream that reads its taps from LDS */
+template <bool FULL, int WAVES, bool SYM>
 __global__ void __launch_bounds__(64 * WAVES)
 timing_fft_kernel(const float2 *__restrict__ x, int nframes, int fpw, int cycles, const float *__restrict__ taps_g,
                   const double2 *__restrict__ tw, const double2 *__restrict__ cs, int32_t *index, float2 *yout, double2 *Xout,
                   double2 *Xk, size_t pitch, int aligned)
 {
     using namespace tfft;
-    __shared__ __attribute__((aligned(16))) float taps[128];
+    __shared__ __attribute__((aligned(16))) float taps[SYM ? 4 : 128];
     __shared__ __attribute__((aligned(16))) float2 wins[WAVES][WSLOTS];
     __shared__ __attribute__((aligned(16))) double2 vfull[FULL ? WAVES : 1][FULL ? NFFT : 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 128) taps[tid] = tid < NTAPS ? taps_g[tid] : 0.0f;
-    __syncthreads();      /* the only workgroup barrier: from here on a wave works on its own */
+    if (!SYM) {
+        if (tid < 128) taps[tid] = tid < NTAPS ? taps_g[tid] : 0.0f;
+        __syncthreads();      /* the only workgroup barrier: from here on a wave works on its own */
+    }
 
     float2 *win = wins[wave];
     const unsigned rd_addr = lds_addr(win + (R + PADS) * lane);      /* position 8 lane -> slot 10 lane */
@@ -97,107 +71,32 @@ timing_fft_kernel(const float2 *__restrict__ x, int nframes, int fpw, int cycles
     const int k0 = NFFT / cycles;                                    /* the symbol-rate bin */
     const int fbase = (blockIdx.x * WAVES + wave) * fpw;             /* this wave's frames: fbase .. fbase + fpw - 1 */
 
-    /* samples N0 - HIST .. N0 + NFFT - 1 = 2 .. 639 as pairs: pair i (samples 2i, 2i+1), i = 1 .. 319, lane l takes 1 + l + 64 j */
     float4 pre[5];
-    auto prefetch = [&](int f) {
-        const float2 *src = x + (size_t)f * pitch;
-        if (aligned) {
-            const float4 *s4 = reinterpret_cast<const float4 *>(src);
-#pragma unroll
-            for (int j = 0; j < 5; j++) pre[j] = s4[min(1 + lane + 64 * j, (N0 + NFFT) / 2 - 1)];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const int i = min(1 + lane + 64 * j, (N0 + NFFT) / 2 - 1);
-                const float2 a = src[2 * i], b = src[2 * i + 1];
-                pre[j] = make_float4(a.x, a.y, b.x, b.y);
-            }
-        }
-    };
-    if (fbase < nframes) prefetch(fbase);
+    if (fbase < nframes) load_frame(x + (size_t)fbase * pitch, lane, aligned, pre);
     for (int it = 0; it < fpw; it++) {
         const int f = fbase + it;
         if (f >= nframes) break;
-        /* window from registers: pair i sits at positions 2 (i - 1), 2 (i - 1) + 1 -- one aligned 16-byte word of the image */
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const int p = 2 * (lane + 64 * j);
-            if (j < 4 || lane < 63) *reinterpret_cast<float4 *>(win + slot_of(p)) = pre[j];
-        }
-        if (it + 1 < fpw && f + 1 < nframes) prefetch(f + 1);
+        stage_frame(win, lane, pre);
+        /* the next frame's samples: in flight during the filter where the registers allow it (256 VGPRs with two waves per SIMD),
+         * behind it with four waves per SIMD (128 VGPRs; the other three waves of the SIMD cover the latency) */
+        if (!SYM && it + 1 < fpw && f + 1 < nframes) load_frame(x + (size_t)(f + 1) * pitch, lane, aligned, pre);
         wave_sync();
         v2f a0, a1, a2, a3, a4, a5, a6, a7;
-        fir_full8_asm(rd_addr, tap_addr, a0, a1, a2, a3, a4, a5, a6, a7);      /* ends with every LDS read returned */
+        if constexpr (SYM) fir_full8s_asm(rd_addr, taps_g, a0, a1, a2, a3, a4, a5, a6, a7);
+        else fir_full8_asm(rd_addr, tap_addr, a0, a1, a2, a3, a4, a5, a6, a7);      /* both end with every LDS read returned */
+        if (SYM && it + 1 < fpw && f + 1 < nframes) load_frame(x + (size_t)(f + 1) * pitch, lane, aligned, pre);
         const v2f acc[R] = {a0, a1, a2, a3, a4, a5, a6, a7};
         double pv[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const float2 y = fir_gain(make_float2(acc[r].x, acc[r].y));          /* rrc_fir.c:28 */
-            if (yout) yout[(size_t)f * NFFT + R * lane + r] = y;                   /* the estimator's view of rrc_fir(): tests compare it with rrc_fir_kernel */
-            const double pr = (double)y.x * (double)y.x, pi = (double)y.y * (double)y.y;
-            pv[r] = pr + pi;
-        }
-        /* transposition through the window's LDS (the stream has finished with it): element o at double slot o + o/8 */
-        double *tp = reinterpret_cast<double *>(win);
-#pragma unroll
-        for (int r = 0; r < R; r++) tp[(R + 1) * lane + r] = pv[r];
-        if (FULL) {
+        const cd u = power_bin(acc, win, lane, tw, k0, yout ? yout + (size_t)f * NFFT : nullptr, pv);
+        if (lane == 0) index[f] = pick_index(u, cs, cycles, Xk ? Xk + f : nullptr);
+        if (FULL) {      /* the whole spectrum as fftn() returns it: fft_lds.h's stages with the wave as the workgroup */
+            double2 *vv = vfull[FULL ? wave : 0];
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int o = R * lane + r;
-                vfull[FULL ? wave : 0][__brev((unsigned)o) >> (32 - LOG2N)] = make_double2(pv[r], 0.0);   /* fft.c:99-101 + the recursion's even/odd order */
+                vv[__brev((unsigned)o) >> (32 - LOG2N)] = make_double2(pv[r], 0.0);   /* fft.c:99-101 + the recursion's even/odd order */
             }
-        }
-        wave_sync();
-        cd v[R];
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int o = lane + 64 * j;
-            v[j].x = tp[o + (o >> 3)];
-            v[j].y = 0.0;
-        }
-        wave_sync();      /* the next frame's staging overwrites tp[] */
-        /* level s: nodes of size m = 2^s, the bin each must deliver is kb = k0 mod m: its twiddle index kb mod m/2 in a size-m
-         * transform = entry (kb mod m/2) * (NFFT / m) of the size-NFFT table (bit-identical: scaling an angle by a power of two is exact) */
-        auto level = [&](int s, double &wr, double &wi, double &sg) {
-            const int m = 1 << s, kb = k0 & (m - 1), kk = kb & (m / 2 - 1);
-            const double2 w = tw[kk << (LOG2N - s)];
-            wr = w.x;
-            wi = -1.0 * w.y;                   /* forward: w = cos - j sin (fft.c:55-56) */
-            sg = kb >= m / 2 ? -1.0 : 1.0;
-        };
-        double wr, wi, sg;
-        level(1, wr, wi, sg);
-#pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = half_butterfly(v[j], v[j + 4], wr, wi, sg);      /* id, id + 256 */
-        level(2, wr, wi, sg);
-#pragma unroll
-        for (int j = 0; j < 2; j++) v[j] = half_butterfly(v[j], v[j + 2], wr, wi, sg);      /* id, id + 128 */
-        level(3, wr, wi, sg);
-        cd u = half_butterfly(v[0], v[1], wr, wi, sg);                                       /* id, id + 64: id = lane */
-#pragma unroll
-        for (int s = 4; s <= LOG2N; s++) {
-            const int delta = 32 >> (s - 4);                                                 /* id, id + 512 / 2^s */
-            cd o;
-            o.x = __shfl_down(u.x, delta);
-            o.y = __shfl_down(u.y, delta);
-            level(s, wr, wi, sg);
-            u = half_butterfly(u, o, wr, wi, sg);
-        }
-        if (lane == 0) {
-            const double dn = (double)NFFT;
-            const double xr = u.x / dn, xi = u.y / dn;       /* fft.c:117-119 */
-            if (Xk) Xk[f] = make_double2(xr, xi);
-            int best = 0;
-            double hmax = xr * cs[0].x - xi * cs[0].y;
-            for (int i = 1; i < cycles; i++) {
-                const double c = xr * cs[i].x - xi * cs[i].y;
-                if (c > hmax) { hmax = c; best = i; }
-            }
-            index[f] = best;
-        }
-        if (FULL) {      /* the whole spectrum as fftn() returns it: fft_lds.h's stages with the wave as the workgroup */
-            double2 *vv = vfull[FULL ? wave : 0];
+            wave_sync();
             for (int s = 1; s <= LOG2N; s++) {
                 const int half = 1 << (s - 1), stride = NFFT >> s;
                 for (int b = lane; b < NFFT / 2; b += 64) {
@@ -221,9 +120,10 @@ timing_fft_kernel(const float2 *__restrict__ x, int nframes, int fpw, int cycles
     }
 }
 
-/* ncu: compute units of the device (one workgroup of 8 waves per CU when the batch allows it) */
+/* ncu: compute units of the device (one workgroup per CU when the batch allows it); symmetric: taps[k] == taps[126 - k] */
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
-                      const double *cs, int32_t *index, float *yout, double *Xout, double *Xk, hipStream_t s, size_t pitch, int ncu)
+                      const double *cs, int32_t *index, float *yout, double *Xout, double *Xk, hipStream_t s, size_t pitch, int ncu,
+                      bool symmetric)
 {
     using namespace tfft;
     if (pitch == 0) pitch = (size_t)frame_size;
@@ -233,19 +133,21 @@ int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, c
     const double2 *tw2 = reinterpret_cast<const double2 *>(tw), *cs2 = reinterpret_cast<const double2 *>(cs);
     if (Xout) {
         constexpr int WV = 4;
-        hipLaunchKernelGGL((timing_fft_kernel<true, WV>), dim3((nframes + WV - 1) / WV), dim3(64 * WV), 0, s, x2, nframes, 1, cycles,
+        hipLaunchKernelGGL((timing_fft_kernel<true, WV, false>), dim3((nframes + WV - 1) / WV), dim3(64 * WV), 0, s, x2, nframes, 1, cycles,
                            taps, tw2, cs2, index, reinterpret_cast<float2 *>(yout), reinterpret_cast<double2 *>(Xout),
                            reinterpret_cast<double2 *>(Xk), pitch, aligned);
     } else {
-        constexpr int WV = 8;
         if (ncu < 1) ncu = 256;
-        int fpw = (nframes + ncu * WV - 1) / (ncu * WV);
-        if (fpw < 1) fpw = 1;
-        if (fpw > MAX_FPW) fpw = MAX_FPW;
-        const int per_wg = WV * fpw;
-        hipLaunchKernelGGL((timing_fft_kernel<false, WV>), dim3((nframes + per_wg - 1) / per_wg), dim3(64 * WV), 0, s, x2, nframes, fpw,
-                           cycles, taps, tw2, cs2, index, reinterpret_cast<float2 *>(yout), nullptr, reinterpret_cast<double2 *>(Xk),
-                           pitch, aligned);
+        auto go = [&](auto kern, int WV) {
+            int fpw = (nframes + ncu * WV - 1) / (ncu * WV);
+            if (fpw < 1) fpw = 1;
+            if (fpw > MAX_FPW) fpw = MAX_FPW;
+            const int per_wg = WV * fpw;
+            hipLaunchKernelGGL(kern, dim3((nframes + per_wg - 1) / per_wg), dim3(64 * WV), 0, s, x2, nframes, fpw, cycles, taps, tw2, cs2,
+                               index, reinterpret_cast<float2 *>(yout), nullptr, reinterpret_cast<double2 *>(Xk), pitch, aligned);
+        };
+        if (symmetric) go(timing_fft_kernel<false, 16, true>, 16);
+        else go(timing_fft_kernel<false, 8, false>, 8);
     }
     return (int)hipGetLastError();
 }

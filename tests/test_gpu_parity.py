@@ -1193,6 +1193,43 @@ def test_fft_timing_pruned_bin_many_frames(oracle, fs, F):
     assert bits_equal(cpu(xk3), cpu(xk)) and np.array_equal(cpu(idx3), cpu(idx2))
 
 
+@pytest.mark.parametrize("F", [4096, 3500, 3329])
+def test_fft_timing_inside_the_receive_launch(oracle, F):
+    """BASELINE config 3's shape (batches that fill rx_fused_pipe_kernel's 16-frame workgroups) runs the FFT estimate INSIDE the
+    receive launch: same indices and same bits as the estimator launched in front (QPSK_FFT_FUSED = 0) and as the oracle, with
+    per-frame timing offsets that differ (frames delayed by 0..7 samples), a ragged last workgroup, and a non-modem frame"""
+    import torch
+    from oracle.pyoracle import TIMING_FFT
+    fs, rs, L = 19200.0, 2400.0, 1024
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT)
+    x, _ = make_frames(F, L + 8, 8, m.taps, fs, offset_hz=30.0, base_seed=11, noise=0.05)
+    x = np.stack([x[f, (f % 8):(f % 8) + L] for f in range(F)])          # every decimation offset occurs
+    x[7] = random_frames(1, L, seed=4)[0]
+    got = m.rx_batch(x, want_costas=True)
+    m.sync()
+    assert m.last_kernel() == "rx_fused_pipe_kernel (FFT timing estimate inside the launch)"
+    m2 = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT)
+    m2.tune(fft_fused=0)
+    sep = m2.rx_batch(x, want_costas=True)
+    m2.sync()
+    assert m2.last_kernel() == "rx_fused_pipe_kernel"
+    for k in ("sym", "phase", "freq", "index", "hz", "costas"):
+        assert bits_equal(cpu(got[k]), cpu(sep[k])), k
+    idx = cpu(got["index"])
+    assert len(np.unique(idx)) == 8
+    pick = np.unique(np.concatenate([np.arange(0, F, 61), [7, F - 1]]))
+    want = oracle.rx_batch(x[pick], fs, rs, loop_bw=BW, timing_mode=TIMING_FFT, want_costas=True)
+    for k in ("sym", "phase", "freq", "index", "hz", "costas"):
+        assert bits_equal(cpu(got[k])[pick], want[k]), k
+    # without an index array the kernel leaves none (the path bench.py times)
+    sym = torch.zeros((F, m.nsym), dtype=torch.uint8, device="cuda")
+    fr = torch.zeros((F,), dtype=torch.float32, device="cuda")
+    ph = torch.zeros_like(fr)
+    m.rx_batch_raw(torch.from_numpy(x).cuda(), F, sym, fr, ph)
+    m.sync()
+    assert bits_equal(cpu(sym), cpu(got["sym"])) and bits_equal(cpu(fr), cpu(got["freq"]))
+
+
 def test_full_size_config3_properties(oracle):
     """BASELINE config 3 at full size (4096 x 16384 with the FFT timing estimate in front): (a) every clean frame's
     estimate is the eye centre 126 mod 8 = 6, (b) so the whole batch equals the fixed-index batch bit for bit, (c) a spread

@@ -23,8 +23,8 @@ from oracle.pyoracle import Oracle, TIMING_FIXED
 from sigutil import make_frames
 rank, local, world = env_rank_world()
 dist = init_distributed("gloo")
-assert dist is not None and dist.get_world_size() == world == 2
-FS, RS, L, TOTAL = 19200.0, 2400.0, 1024, 11           # 11 frames: uneven split 5 + 6
+assert dist is not None and dist.get_world_size() == world == int(os.environ["EXPECT_WORLD"])
+FS, RS, L, TOTAL = 19200.0, 2400.0, 1024, 8 * world - 5   # uneven split: 5 + 6 frames on two ranks, 7 + 7 x 8 ... on eight
 orc = Oracle()
 taps = orc.rrc_make(FS, RS, np.float32(.35))
 lo, hi = shard_range(TOTAL, rank, world)
@@ -75,13 +75,15 @@ def test_shard_ranges_tile_the_batch():
         shard_range(10, 2, 2)
 
 
-def test_two_ranks_over_gloo(tmp_path, oracle):
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_over_gloo(tmp_path, oracle, world):
+    """world = 8: the control plane of BASELINE config 4 (65536 frames over 8 GPUs) at its real rank count"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     port = free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), EXPECT_WORLD=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
