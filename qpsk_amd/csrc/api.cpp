@@ -67,6 +67,8 @@ struct Tuning {
     int pipe_variant = -1;                            /* pipeline kernel: layout bits (kernels.h, FusedArgs::dbg) */
     int hist_generic = -1;                            /* histogram estimate: 1 = rrc_fir + scan kernels (no fused scan), 2 = those with the generic scan */
     int fir_generic = -1;                             /* full-rate rrc_fir(): 1 = the compiler-scheduled rrc_fir_kernel also for symmetric taps */
+    int stream_poll = -1;                             /* qpsk_streams_rx_pcm_host on the one-launch kernel: 0 = wait with hipStreamSynchronize instead of watching the kernel's counter */
+    int stream_block = -1;                            /* streams: 0 = never the one-launch-per-block kernel (streamblock.hip), 1 = whenever the shape allows, unset: up to 1024 streams */
     int fft_fused = -1;                               /* FFT timing estimate: 0 = always a launch of its own (1 / unset: inside rx_fused_pipe_kernel's launch for full workgroups) */
 };
 
@@ -77,6 +79,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
     {"QPSK_PIPE_V", &Tuning::pipe_v},         {"QPSK_PIPE_G", &Tuning::pipe_g},
     {"QPSK_PIPE_LAYOUT_LO", &Tuning::layout_lo}, {"QPSK_PIPE_LAYOUT_HI", &Tuning::layout_hi},
     {"QPSK_FIR_GENERIC", &Tuning::fir_generic}, {"QPSK_FFT_FUSED", &Tuning::fft_fused},
+    {"QPSK_STREAM_BLOCK", &Tuning::stream_block}, {"QPSK_STREAM_POLL", &Tuning::stream_poll},
 };
 
 /* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
@@ -106,6 +109,8 @@ struct qpsk_ctx {
      * its results are invalid (its in-LDS pipeline exhausted the bounded spins; a loop phase beyond the bounded
      * 2 pi wrap).  The host looks at it after EVERY synchronisation the library performs (check_status), so no
      * entry point that hands results to the caller can return QPSK_OK over invalid ones. */
+    unsigned *h_done = nullptr, *d_done = nullptr;   /* stream_block_kernel's wave counter (mapped pinned memory), host / device view */
+    unsigned done_expect = 0;
     int *h_status = nullptr;     /* host view */
     int *d_status = nullptr;     /* device view of the same word */
     std::vector<float> h_gains;
@@ -250,6 +255,7 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
     KERNEL_TRY(prepare_kernels());
     KERNEL_TRY(prepare_pipe_kernel());
     KERNEL_TRY(prepare_timing_scan());
+    KERNEL_TRY(prepare_stream_block());
     qpsk_ctx *c = new qpsk_ctx();
     c->device = device;
     for (const auto &k : TUNING_KEYS) {   /* the only place the environment is read */
@@ -278,6 +284,12 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
         return fail(QPSK_ERR_ALLOC, "hipMalloc of configuration buffers failed");
     }
     *c->h_status = 0;
+    if (hipHostMalloc((void **)&c->h_done, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->d_done, c->h_done, 0) != hipSuccess) {
+        qpsk_ctx_destroy(c);
+        return fail(QPSK_ERR_ALLOC, "pinned counter");
+    }
+    *c->h_done = 0;
     int rc = upload_config(c);
     if (rc != QPSK_OK) { qpsk_ctx_destroy(c); return rc; }
     *out = c;
@@ -312,6 +324,7 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
     hipFree(c->d_taps);
     hipFree(c->d_gains);
     if (c->h_status) hipHostFree(c->h_status);
+    if (c->h_done) hipHostFree(c->h_done);
     hipFree(c->index.p);
     hipFree(c->filtered.p);
     hipFree(c->mixed.p);
@@ -955,12 +968,69 @@ int qpsk_streams_get_loop_state(qpsk_ctx *c, float *h_state)
     return check_status(c);
 }
 
+/* One launch per block (streamblock.hip) instead of the five-kernel composition: few, short streams -- the reference's call
+ * pattern, where the launches are the cost.  Histogram or fixed timing (the FFT estimate keeps its own kernel). */
+static bool stream_block_ok(const qpsk_ctx *c)
+{
+    const int t = tuned(c->tune.stream_block, -1);
+    if (t == 0 || c->prm.timing_mode == QPSK_TIMING_FFT || c->prm.frame_size > stream_block_max_frame() ||
+        c->nsym * c->cycles > c->prm.frame_size || tuned(c->tune.generic, 0) != 0 ||
+        stream_block_lds_bytes(c->prm.frame_size, c->nsym) > (size_t)MAX_LDS_BYTES)
+        return false;
+    return t == 1 || c->nstreams <= 1024;
+}
+
+/* pcm / cplx: exactly one of them; every pointer device-visible (device memory or mapped pinned host memory) */
+static int streams_block_launch(qpsk_ctx *c, const int16_t *pcm, const float *cplx, const float *loop_in, float *loop_out,
+                                uint8_t *sym, float *costas, int32_t *index, const StreamBlockInline *inl = nullptr, bool count = false)
+{
+    if (int rg = use_context_gains(c)) return rg;
+    StreamBlockArgs a{};
+    a.pcm = pcm;
+    a.cplx = reinterpret_cast<const float2 *>(cplx);
+    a.mixer = c->s_mixer;
+    a.memory = reinterpret_cast<float2 *>(c->s_memory);
+    a.dec = reinterpret_cast<float2 *>(c->s_dec);
+    a.loop = c->s_loop;
+    a.loop_in = loop_in;
+    a.loop_out = loop_out;
+    a.taps = c->d_taps;
+    a.gains = c->d_gains;
+    a.min_freq = c->min_freq;
+    a.max_freq = c->max_freq;
+    a.frame_size = c->prm.frame_size;
+    a.cycles = c->cycles;
+    a.nsym = c->nsym;
+    a.hist_timing = c->prm.timing_mode == QPSK_TIMING_HIST;
+    a.fixed_index = c->prm.fixed_index;
+    a.sym = sym;
+    a.costas = reinterpret_cast<float2 *>(costas);
+    a.index = index;
+    a.status = c->d_status;
+    a.done = count ? c->d_done : nullptr;
+    KERNEL_TRY(launch_stream_block(a, c->nstreams, c->stream, inl));
+    c->last_kernel = "stream_block_kernel";
+    return QPSK_OK;
+}
+
+static int streams_copy_loop(qpsk_ctx *c, float *d_freq, float *d_phase)
+{
+    const int n = c->nstreams;
+    if (d_phase) HIP_TRY(hipMemcpy2DAsync(d_phase, sizeof(float), c->s_loop, 2 * sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, c->stream));
+    if (d_freq) HIP_TRY(hipMemcpy2DAsync(d_freq, sizeof(float), c->s_loop + 1, 2 * sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, c->stream));
+    return QPSK_OK;
+}
+
 int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *d_freq, float *d_phase,
                          float *d_costas, int32_t *d_index)
 {
     if (!c || !d_in) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_cplx: null argument");
     if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
     if (bind(c)) return QPSK_ERR_HIP;
+    if (d_sym && stream_block_ok(c)) {
+        if (int rb = streams_block_launch(c, nullptr, d_in, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
+        return streams_copy_loop(c, d_freq, d_phase);
+    }
     const int n = c->nstreams, L = c->prm.frame_size, N = c->nsym;
     int rc = ensure(c, c->filtered, sizeof(float) * 2 * (size_t)n * L);
     if (rc) return rc;
@@ -984,9 +1054,7 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
     rc = costas_over_symbols(c, c->s_dec, n, N, N, c->s_loop, d_sym, d_costas, filt, idx);
     if (rc) return rc;
     if (d_index) HIP_TRY(hipMemcpyAsync(d_index, idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-    if (d_phase) HIP_TRY(hipMemcpy2DAsync(d_phase, sizeof(float), c->s_loop, 2 * sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, c->stream));
-    if (d_freq) HIP_TRY(hipMemcpy2DAsync(d_freq, sizeof(float), c->s_loop + 1, 2 * sizeof(float), sizeof(float), n, hipMemcpyDeviceToDevice, c->stream));
-    return QPSK_OK;
+    return streams_copy_loop(c, d_freq, d_phase);
 }
 
 int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float *d_freq, float *d_phase,
@@ -995,6 +1063,10 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
     if (!c || !d_pcm) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_pcm: null argument");
     if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
     if (bind(c)) return QPSK_ERR_HIP;
+    if (d_sym && stream_block_ok(c)) {
+        if (int rb = streams_block_launch(c, d_pcm, nullptr, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
+        return streams_copy_loop(c, d_freq, d_phase);
+    }
     const int n = c->nstreams, L = c->prm.frame_size;
     int rc = ensure(c, c->mixed, sizeof(float) * 2 * (size_t)n * L);
     if (rc) return rc;
@@ -1038,6 +1110,42 @@ int qpsk_streams_rx_pcm_host(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io
     }
     if (h_loop_io) memcpy(c->h_stage + o_loop, h_loop_io, 8 * n);
     memcpy(c->h_stage + o_pcm, h_pcm, 2 * n * L);
+    if (stream_block_ok(c)) {
+        /* one launch, no copy engine: the kernel reads the PCM (and the loop state) from the pinned staging buffer and leaves its
+         * results there -- a kilobyte in, a few hundred bytes out per stream */
+        unsigned char *m = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&m, c->h_stage, 0));
+        /* a block of up to 2 KB rides in the kernel arguments (device memory the host writes into): the kernel then reads no host
+         * memory at all -- a read of pinned host memory from the GPU costs 8-14 us on this pool, a posted write a fraction of that */
+        StreamBlockInline inl;
+        const bool use_inl = n <= (size_t)StreamBlockInline::MAX_STREAMS && n * L <= (size_t)StreamBlockInline::MAX_SAMPLES;
+        if (use_inl) {
+            if (h_loop_io) memcpy(inl.loop, h_loop_io, 8 * n);
+            memcpy(inl.pcm, h_pcm, 2 * n * L);
+        }
+        if (int rb = streams_block_launch(c, (const int16_t *)(m + o_pcm), nullptr, h_loop_io ? (const float *)(m + o_loop) : nullptr,
+                                          (float *)(m + o_lout), m + o_sym, h_costas ? (float *)(m + o_cos) : nullptr, (int32_t *)(m + o_idx),
+                                          use_inl ? &inl : nullptr, tuned(c->tune.stream_poll, 1) != 0))
+            return rb;
+        if (tuned(c->tune.stream_poll, 1) != 0) {
+            /* the kernel's two waves per stream count themselves off in pinned memory behind their last store: watching that word
+             * is quicker than the stream's completion signal.  Bounded: after ~2 s the ordinary synchronisation takes over. */
+            c->done_expect += 2u * (unsigned)n;
+            const volatile unsigned *dn = c->h_done;
+            long spins = 0;
+            while ((int)(*dn - c->done_expect) < 0 && ++spins < 400000000L) __builtin_ia32_pause();
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            if ((int)(*dn - c->done_expect) < 0) HIP_TRY(hipStreamSynchronize(c->stream));
+        } else {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        if (int st = check_status(c)) return st;
+        memcpy(h_sym, c->h_stage + o_sym, n * N);
+        if (h_costas) memcpy(h_costas, c->h_stage + o_cos, 8 * n * N);
+        if (h_loop_io) memcpy(h_loop_io, c->h_stage + o_lout, 8 * n);
+        if (h_index) memcpy(h_index, c->h_stage + o_idx, 4 * n);
+        return QPSK_OK;
+    }
     const size_t up0 = h_loop_io ? o_loop : o_pcm;
     HIP_TRY(hipMemcpyAsync(c->d_stage + up0, c->h_stage + up0, in_bytes - up0, hipMemcpyHostToDevice, c->stream));
     if (h_loop_io) HIP_TRY(hipMemcpyAsync(c->s_loop, c->d_stage + o_loop, 8 * n, hipMemcpyDeviceToDevice, c->stream));

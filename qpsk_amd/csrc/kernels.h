@@ -124,6 +124,40 @@ int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, c
                       pruned one), Xk [nframes][2] the symbol-rate bin as the pruned transform delivers it */
 int timing_fft_nfft(void);
 int timing_fft_first(void);
+/* streamblock.hip: one launch per rx_frame() block and stream (few, short streams: the reference's call pattern) */
+struct StreamBlockArgs {
+    const int16_t *pcm;     /* [n][frame_size] PCM (device memory or mapped pinned host memory), or NULL: */
+    const float2 *cplx;     /* [n][frame_size] complex samples at the rrc_fir() call (qpsk.c:125) */
+    float *mixer;           /* [n][4] carrier phase and step (PCM input), in/out */
+    float2 *memory;         /* [n][127] delay lines, in/out */
+    float2 *dec;            /* [n][nsym] decimated_frame[]: the previous block's picks in, this block's out */
+    float *loop;            /* [n][2] phase, freq in/out */
+    const float *loop_in;   /* [n][2] or NULL: loop state to start from instead of `loop` (host staging) */
+    float *loop_out;        /* [n][2] or NULL: a second copy of the final state (host staging) */
+    const float *taps, *gains;   /* [127]; [2] alpha, beta */
+    float min_freq, max_freq;
+    int frame_size, cycles, nsym, hist_timing, fixed_index;
+    uint8_t *sym;           /* [n][nsym] */
+    float2 *costas;         /* [n][nsym] or NULL */
+    int32_t *index;         /* [n] or NULL */
+    float2 *filtered;       /* [n][frame_size] or NULL */
+    int *status;
+    unsigned *done;         /* mapped pinned host counter or NULL: every wave adds 1 behind its last store (system scope), so the host
+                               can watch the block finish instead of going through the stream's completion signal */
+};
+/* Blocks small enough travel INSIDE the kernel arguments (the dispatch packet's argument buffer is device memory the host writes
+ * through the PCIe aperture: posted writes), so the kernel never reads host memory -- on this pool a read of pinned host memory
+ * from the GPU takes 8-14 us, the whole budget of a 512-sample block [measured, profiles/r04_stream_block.txt] */
+struct StreamBlockInline {
+    static constexpr int MAX_STREAMS = 8, MAX_SAMPLES = 1024;      /* n <= 8 streams, n * frame_size <= 1024 samples (2 KB) */
+    float loop[2 * MAX_STREAMS];
+    uint4 pcm[MAX_SAMPLES / 8];
+};
+size_t stream_block_lds_bytes(int frame_size, int nsym);
+int stream_block_max_frame(void);
+int prepare_stream_block(void);
+int launch_stream_block(const StreamBlockArgs &a, int nstreams, hipStream_t s, const StreamBlockInline *inl = nullptr);   /* inl: PCM and, if
+                        a.loop_in is set (to anything), the loop state come from *inl instead of a.pcm / a.loop_in */
 /* bitstages.hip */
 int launch_crc16(const uint8_t *data, int npackets, int nbytes, uint16_t *crc, hipStream_t s);
 int launch_interleave(uint8_t *data, int npackets, int nbytes, unsigned b, int dir, hipStream_t s);

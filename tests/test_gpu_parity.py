@@ -923,11 +923,15 @@ def test_tx_requires_reset():
 
 
 # ------------------------------------------------------------------ streams (consecutive rx_frame calls)
+@pytest.mark.parametrize("block", [1, 0])
 @pytest.mark.parametrize("name", ["shipped", "c1small"])
-def test_streams_pcm_golden(name):
+def test_streams_pcm_golden(name, block):
+    """consecutive rx_frame() calls against the reference's recordings: block = 1 the one-launch-per-block kernel
+    (streamblock.hip: what few short streams get), 0 the five-kernel composition"""
     g = golden("stream_pcm_%s.npz" % name)
     L = int(g["frame_size"])
     m = modem(fs=float(g["fs"]), rs=float(g["rs"]), frame_size=L, loop_bw=np.float32(g["loop_bw"]))
+    m.tune(stream_block=block)
     m.streams_reset(3, 1500.0)
     for k in range(g["sym"].shape[0]):
         blk = np.repeat(g["pcm"][k * L:(k + 1) * L][None], 3, 0)
@@ -937,6 +941,7 @@ def test_streams_pcm_golden(name):
             assert cpu(o["index"])[s] == g["index"][k]
             assert bits_equal(cpu(o["sym"][s]), g["sym"][k]) and bits_equal(cpu(o["costas"][s]), g["costas"][k])
             assert cpu(o["phase"])[s] == g["phase"][k] and cpu(o["freq"])[s] == g["freq"][k]
+    assert (m.last_kernel() == "stream_block_kernel") == bool(block)
 
 
 def test_streams_with_fft_timing(oracle):
@@ -959,13 +964,16 @@ def test_streams_with_fft_timing(oracle):
             assert cpu(o["phase"])[s] == om[s].phase and cpu(o["freq"])[s] == om[s].freq
 
 
-@pytest.mark.parametrize("generic", [0, 1])
-def test_streams_cplx_vs_oracle(oracle, generic):
-    """generic = 1: the barrier-synchronised kernels (decimate_kernel + costas_kernel) instead of the pipeline"""
-    fs, rs, L, S = 19200.0, 2400.0, 1024, 9
+@pytest.mark.parametrize("generic,L,S", [(0, 1024, 9), (1, 1024, 9), (2, 1024, 9), (2, 2048, 70), (2, 1000, 3), (0, 4096, 5)])
+def test_streams_cplx_vs_oracle(oracle, generic, L, S):
+    """generic = 1: the barrier-synchronised kernels (decimate_kernel + costas_kernel) instead of the pipeline; 0: the
+    five-kernel composition with the pipeline kernel; 2: the one-launch-per-block kernel (the library's own choice for few
+    short streams), also with a frame that is not whole 512-sample tiles or whole 16-symbol groups"""
+    fs, rs = 19200.0, 2400.0
     m = modem(fs=fs, rs=rs, frame_size=L)
-    if generic:
+    if generic == 1:
         m.tune(fused_generic=1)
+    m.tune(stream_block=1 if generic == 2 else 0)
     m.streams_reset(S)
     om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
     x, _ = make_frames(S, L * 5, 8, m.taps, fs, offset_hz=30.0, base_seed=17, noise=0.02)
@@ -978,6 +986,7 @@ def test_streams_cplx_vs_oracle(oracle, generic):
             assert cpu(o["index"])[s] == om[s].index
             assert bits_equal(cpu(o["sym"][s]), om[s].symbols) and bits_equal(cpu(o["costas"][s]), om[s].costas_frame)
             assert cpu(o["phase"])[s] == om[s].phase and cpu(o["freq"])[s] == om[s].freq
+    assert (m.last_kernel() == "stream_block_kernel") == (generic == 2)
 
 
 # ------------------------------------------------------------------ robustness of the product library
