@@ -1499,15 +1499,17 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
             printf("wg %3d FIR wave hw %2d (%d units): %d chunks, %llu cycles in the stream; per chunk: samples %u, stage+loads %u, "
                    "filter+gain %u, wait for the loop %u, flush %u, hand-over %u\n", (int)blockIdx.x, hwave, NUW, nchunks, t1 - t0,
                    pf[0] / nchunks, pf[1] / nchunks, pf[2] / nchunks, pf[3] / nchunks, pf[4] / nchunks, pf[5] / nchunks);
-    } else if (a.dbg & (1 | 16384 | 32768)) {
+    } else if (a.dbg & (1 | 16384 | 32768 | 65536)) {
         /* measurement build: streams with a part of the work left out (WRONG results): 1 the filter's multiplies and adds,
-         * 16384 its window reads, 32768 the flush's arithmetic -- what each costs in time at the board's power limit */
+         * 16384 its window reads, 32768 the flush's arithmetic, 65536 the window staging writes -- what each costs in time and
+         * in energy at the board's power limit (one at a time: the first bit set wins) */
 #define QPSK_LEAN_ABLATED(SFX)                                                                                          \
         (NUW == 2 ? fir_lean_loop2_##SFX(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w)    \
                   : fir_lean_loop1_##SFX(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w))
         if (a.dbg & 1) st = QPSK_LEAN_ABLATED(avalu);
         else if (a.dbg & 16384) st = QPSK_LEAN_ABLATED(alds);
-        else st = QPSK_LEAN_ABLATED(aflush);
+        else if (a.dbg & 32768) st = QPSK_LEAN_ABLATED(aflush);
+        else st = QPSK_LEAN_ABLATED(astage);
 #undef QPSK_LEAN_ABLATED
     } else
 #endif

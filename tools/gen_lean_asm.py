@@ -3,7 +3,7 @@
 one gfx950 instruction stream per wave shape (1 or 2 two-frame units per wave).
 
     python tools/gen_lean_asm.py > qpsk_amd/csrc/fir_lean_asm.h
-    python tools/gen_lean_asm.py --profile > qpsk_amd/csrc/fir_lean_prof_asm.h      (measurement build only)
+    python tools/gen_lean_asm.py --profile > qpsk_amd/csrc/build/fir_lean_prof_asm.h   (measurement build only: `make profile` does this)
 
 What one iteration of the loop does for one unit (2 frames x 64 symbols of chunk c; reference rrc_fir.c:17-30 evaluated at
 the samples qpsk.c:190 keeps, then the slicer of qpsk.c:74-79 on the loop's de-rotated symbols, qpsk.c:197):
@@ -207,6 +207,11 @@ def stage_frame(e, ui, ff):
     sh = 4 * (2 * ui + ff)
     wr0, wr1 = "%%[w0_%d%d]" % (ui, ff), "%%[w1_%d%d]" % (ui, ff)
     hist = HIST + 8 * ui + 4 * ff
+    if ABLATE == "stage":      # no window writes at all: the filter reads whatever the LDS holds (only the history registers move on)
+        r = PRE + 16 * ff + 12
+        e("v_mov_b64 %s, %s", vp(hist), vp(r))
+        e("v_mov_b64 %s, %s", vp(hist + 2), vp(r + 2))
+        return
     odd, done = e.label("odd"), e.label("stg")
     e("s_bfe_u32 s%d, s%d, 0x4%04x", ST0, SIX, sh)             # the frame's decimation offset
     e("s_lshr_b32 s%d, s%d, 1", ST1, ST0)
@@ -551,7 +556,7 @@ constexpr int FIR_LEAN_NPROF = %d;
     print(emit_function(1))
     print(emit_function(2))
     global ABLATE
-    for ABLATE in ("valu", "lds", "flush"):
+    for ABLATE in ("valu", "lds", "flush", "stage"):
         print(emit_function(1))
         print(emit_function(2))
     ABLATE = None

@@ -37,6 +37,25 @@ print("child: %%d frames, dbg %%d %%s, %%s, %%.4f ms per launch (last 500), %%d 
 ''' % ROOT
 
 
+def amd_smi():
+    """socket power, per-XCD clocks and the power-tracking (PPT) throttle activity from amd-smi, where it exists"""
+    try:
+        r = subprocess.run(["amd-smi", "metric", "-g", "0"], capture_output=True, text=True, timeout=30).stdout
+    except Exception:      # noqa: BLE001
+        return ""
+    import re
+    pw = re.search(r"SOCKET_POWER: (\d+) W", r)
+    ppt = re.search(r"PPT_VIOLATION_ACTIVITY: (\S+ ?%?)", r)
+    st = re.search(r"PPT_VIOLATION_STATUS: (\S+ ?\S*)", r)
+    clk = [int(x) for x in re.findall(r"GFX_\d:\s+CLK: (\d+) MHz", r)]
+    umc = re.search(r"UMC_ACTIVITY: (\d+) %", r)
+    if not pw:
+        return ""
+    return " | amd-smi: %s W, XCD clocks %d-%d MHz (mean %d), PPT violation %s (%s), UMC activity %s %%" % (
+        pw.group(1), min(clk) if clk else 0, max(clk) if clk else 0, sum(clk) // max(1, len(clk)), st.group(1).strip() if st else "?",
+        ppt.group(1).strip() if ppt else "?", umc.group(1) if umc else "?")
+
+
 def smi():
     out = []
     for args in (["--showpower"], ["--showclocks"]):
@@ -57,7 +76,7 @@ if args and args[0] == "--cmd":      # any program that prints a line when it ha
         p = subprocess.Popen(cmd.split(), stdout=subprocess.PIPE, text=True)
         time.sleep(2.5)
         for i in range(2):
-            print("%s, t+%ds: %s" % (cmd, i + 2, smi()), flush=True)
+            print("%s, t+%ds: %s%s" % (cmd, i + 2, smi(), amd_smi() if i == 1 else ""), flush=True)
             time.sleep(0.5)
         print(p.stdout.read().strip(), flush=True)
         p.wait()
@@ -65,11 +84,11 @@ if args and args[0] == "--cmd":      # any program that prints a line when it ha
 for arg in args or ["4096", "8192"]:
     parts = arg.split(":")
     frames, dbg, tune = int(parts[0]), int(parts[1] or "0", 0) if len(parts) > 1 else 0, parts[2] if len(parts) > 2 else ""
-    p = subprocess.Popen([sys.executable, "-c", CHILD, str(frames), "5", str(dbg), tune], stdout=subprocess.PIPE, text=True)
+    p = subprocess.Popen([sys.executable, "-c", CHILD, str(frames), "7", str(dbg), tune], stdout=subprocess.PIPE, text=True)
     p.stdout.readline()
     time.sleep(1.5)
     for i in range(2):
-        print("%d frames, dbg %d, t+%ds: %s" % (frames, dbg, i + 1, smi()), flush=True)
+        print("%d frames, dbg %d, t+%ds: %s%s" % (frames, dbg, i + 1, smi(), amd_smi() if i == 1 else ""), flush=True)
         time.sleep(0.5)
     print(p.stdout.read().strip(), flush=True)
     p.wait()
