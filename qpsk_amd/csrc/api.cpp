@@ -512,7 +512,7 @@ static int timing_indices(qpsk_ctx *c, const float *d_in, size_t pitch, int nfra
          * once here and once by the pipeline kernel that follows, nothing is written but the index */
         if (scan_fused_ok(c, d_in) && (pitch & 1) == 0) {
             KERNEL_TRY(launch_timing_scan(d_in, nframes, c->prm.frame_size, c->d_taps, (int32_t *)c->index.p, nullptr,
-                                          c->d_status, c->stream, pitch));
+                                          c->d_status, c->stream, pitch, c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0));
             *d_index_out = (const int32_t *)c->index.p;
             return QPSK_OK;
         }
@@ -855,7 +855,8 @@ int qpsk_timing_scan_batch(qpsk_ctx *c, const float *d_in, int nframes, int32_t 
     if (!(c->cycles == 8 && c->prm.frame_size % timing_scan_tile() == 0 && ((uintptr_t)d_in % 16) == 0))
         return fail(QPSK_ERR_ARG, "qpsk_timing_scan_batch needs CYCLES = 8, frame_size %% %d == 0 and 16-byte aligned input "
                                   "(use qpsk_rrc_fir_batch + qpsk_timing_hist_batch otherwise)", timing_scan_tile());
-    KERNEL_TRY(launch_timing_scan(d_in, nframes, c->prm.frame_size, c->d_taps, d_index, d_hist, c->d_status, c->stream));
+    KERNEL_TRY(launch_timing_scan(d_in, nframes, c->prm.frame_size, c->d_taps, d_index, d_hist, c->d_status, c->stream, 0,
+                                  c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0));
     return QPSK_OK;
 }
 

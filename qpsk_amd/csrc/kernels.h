@@ -115,7 +115,7 @@ size_t timing_scan_lds_bytes(void);
 int timing_scan_tile(void);
 int prepare_timing_scan(void);
 int launch_timing_scan(const float *x, int nframes, int frame_size, const float *taps, int32_t *index, int32_t *hist,
-                       int *status, hipStream_t s, size_t pitch = 0);
+                       int *status, hipStream_t s, size_t pitch = 0, bool symmetric = false);   /* symmetric taps: the SGPR-tap stream */
 /* timing_fft.hip */
 int launch_timing_fft(const float *x, int nframes, int frame_size, int cycles, const float *taps, const double *tw,
                       const double *cs, int32_t *index, float *yout, double *Xout, double *Xk, hipStream_t s, size_t pitch = 0,

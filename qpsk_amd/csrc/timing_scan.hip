@@ -31,6 +31,7 @@
 #include "qpsk_device.h"
 #include "costas_asm.h"      /* lds_addr() */
 #include "fir_full8_asm.h"
+#include "fir_full8s_asm.h"
 static_assert(qpsk::FIR_FULL8_ASM_END_VGPR <= 168, "timing_scan_kernel: 12 waves per workgroup = three per SIMD = at most 168 VGPRs (regenerate fir_full8_asm.h from VGPR 80, tools/gen_fir_asm.py)");
 #include "kernels.h"
 
@@ -81,6 +82,8 @@ __device__ __forceinline__ void publish(int *p, int v)
 }
 } // namespace tscan
 
+/* SYM: the filter is symmetric (host-checked): the stream with its taps in SGPRs (fir_full8s_asm.h: no tap reads from LDS) */
+template <bool SYM>
 __global__ void __launch_bounds__(tscan::THREADS)
 timing_scan_kernel(const float2 *__restrict__ x, int nframes, int frame_size, const float *__restrict__ taps_g,
                    int32_t *index, int32_t *hist_out, int *status, size_t pitch)
@@ -221,7 +224,8 @@ timing_scan_kernel(const float2 *__restrict__ x, int nframes, int frame_size, co
         if (t + 1 < ntiles) prefetch(t + 1);
         tick(0);
         v2f a0, a1, a2, a3, a4, a5, a6, a7;
-        fir_full8_asm(rd_addr, tap_addr, a0, a1, a2, a3, a4, a5, a6, a7);
+        if constexpr (SYM) fir_full8s_asm(rd_addr, taps_g, a0, a1, a2, a3, a4, a5, a6, a7);
+        else fir_full8_asm(rd_addr, tap_addr, a0, a1, a2, a3, a4, a5, a6, a7);
         tick(1);
         /* the ring slot is free once the scan wave of this frame has finished tile t - DRO */
         if (t >= DRO) ok = wait_ge(&sm->consumed[g >> 2], t - DRO + 1, &sm->abort_flag);
@@ -259,19 +263,26 @@ int timing_scan_tile(void) { return tscan::TILE; }
 
 int prepare_timing_scan(void)
 {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(timing_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(timing_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(timing_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     MAX_LDS_BYTES);
 }
 
 /* frame_size % 256 == 0, CYCLES = 8, x 16-byte aligned (host-checked) */
 int launch_timing_scan(const float *x, int nframes, int frame_size, const float *taps, int32_t *index, int32_t *hist,
-                       int *status, hipStream_t s, size_t pitch)
+                       int *status, hipStream_t s, size_t pitch, bool symmetric)
 {
     using namespace tscan;
     if (pitch == 0) pitch = (size_t)frame_size;
     if (frame_size % TILE != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (pitch & 1)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(timing_scan_kernel, dim3((nframes + G - 1) / G), dim3(THREADS), timing_scan_lds_bytes(), s,
-                       reinterpret_cast<const float2 *>(x), nframes, frame_size, taps, index, hist, status, pitch);
+    if (symmetric)
+        hipLaunchKernelGGL(timing_scan_kernel<true>, dim3((nframes + G - 1) / G), dim3(THREADS), timing_scan_lds_bytes(), s,
+                           reinterpret_cast<const float2 *>(x), nframes, frame_size, taps, index, hist, status, pitch);
+    else
+        hipLaunchKernelGGL(timing_scan_kernel<false>, dim3((nframes + G - 1) / G), dim3(THREADS), timing_scan_lds_bytes(), s,
+                           reinterpret_cast<const float2 *>(x), nframes, frame_size, taps, index, hist, status, pitch);
     return (int)hipGetLastError();
 }
 
