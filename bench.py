@@ -96,7 +96,8 @@ def cpu_baseline(x_host, taps):
     from oracle.pyoracle import Oracle, Reference, TIMING_HIST, ref_available
     nsamp = x_host.shape[0] * x_host.shape[1]
     out = {}
-    if ref_available("c1"):
+    have_ref = bool(ref_available("c1"))
+    if have_ref:
         ref = Reference("c1")
         ref.reset()
         t0 = time.perf_counter()
@@ -122,6 +123,9 @@ def cpu_baseline(x_host, taps):
         out = dict(value=port["port_1core_msps"], unit="Msamples/s", cores=1, kind="port",
                    sample="%d frames x %d samples, oracle restatement" % x_host.shape[:2])
     out.update(port)
+    # oracle/_ref/*.so is built in the build container from /root/reference and is git-ignored: on a checkout where it did not
+    # travel the line's kind silently becomes "port" -- say which it was
+    out["ref_so"] = "present" if have_ref else "absent (kind falls back to the oracle port)"
     return out
 
 

@@ -1118,6 +1118,9 @@ int qpsk_streams_rx_pcm_host(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io
         HIP_TRY(hipHostGetDevicePointer((void **)&m, c->h_stage, 0));
         /* a block of up to 2 KB rides in the kernel arguments (device memory the host writes into): the kernel then reads no host
          * memory at all -- a read of pinned host memory from the GPU costs 8-14 us on this pool, a posted write a fraction of that */
+        /* few streams: the waves count themselves off in pinned memory (a system-scope atomic each: ~1 us apiece over PCIe, so only
+         * for a handful -- 64 streams took 156 us that way against 47 with the stream's own completion signal) */
+        const bool poll = tuned(c->tune.stream_poll, n <= (size_t)StreamBlockInline::MAX_STREAMS ? 1 : 0) != 0;
         StreamBlockInline inl;
         const bool use_inl = n <= (size_t)StreamBlockInline::MAX_STREAMS && n * L <= (size_t)StreamBlockInline::MAX_SAMPLES;
         if (use_inl) {
@@ -1126,9 +1129,9 @@ int qpsk_streams_rx_pcm_host(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io
         }
         if (int rb = streams_block_launch(c, (const int16_t *)(m + o_pcm), nullptr, h_loop_io ? (const float *)(m + o_loop) : nullptr,
                                           (float *)(m + o_lout), m + o_sym, h_costas ? (float *)(m + o_cos) : nullptr, (int32_t *)(m + o_idx),
-                                          use_inl ? &inl : nullptr, tuned(c->tune.stream_poll, 1) != 0))
+                                          use_inl ? &inl : nullptr, poll))
             return rb;
-        if (tuned(c->tune.stream_poll, 1) != 0) {
+        if (poll) {
             /* the kernel's two waves per stream count themselves off in pinned memory behind their last store: watching that word
              * is quicker than the stream's completion signal.  Bounded: after ~2 s the ordinary synchronisation takes over. */
             c->done_expect += 2u * (unsigned)n;

@@ -64,6 +64,8 @@ def test_bench_json_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["ref_so"].startswith("present") == (cb["kind"] == "reference")      # the line says whether oracle/_ref travelled
+    assert "stimulus" in d and "qpsk_tx_symbols" in d["stimulus"]                  # frames from the library's own transmit chain
     p = d["parity"]
     assert p["symbol_mismatches"] == 0 and p["freq_bit_mismatches"] == 0 and p["phase_bit_mismatches"] == 0
     assert p["hz_frames_checked"] == 256 and p["hz_out_of_range"] == 0       # EVERY frame locked on the +50 Hz carrier

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Measurement helper (GPU box): one library call back to back for some seconds, steady-state ms per call -- the child of
-`tools/power_probe.py --cmd "python3 tools/loop_kernel.py <what> [secs] [frames]"` (board power and shader clock beside it).
+`tools/power_probe.py --cmd "python3 tools/loop_kernel.py <what> [secs] [frames] [launches per loop]"` (board power and shader clock beside it).
 
     what: fir (qpsk_rrc_fir_batch, the stream kernel)   fir_generic (the compiler-scheduled rrc_fir_kernel)
           fft_est (qpsk_timing_fft_bin_batch)           scan (qpsk_timing_scan_batch)
@@ -19,6 +19,7 @@ import qpsk_amd  # noqa: E402
 what = sys.argv[1]
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
 F = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+per = int(sys.argv[4]) if len(sys.argv) > 4 else 200      # launches between two synchronisations (counter passes: a handful, with secs = 0)
 dev = torch.device("cuda", 0)
 mode = {"config3": qpsk_amd.TIMING_FFT, "fft_est": qpsk_amd.TIMING_FFT, "hist": qpsk_amd.TIMING_HIST}.get(what, qpsk_amd.TIMING_FIXED)
 m = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=mode, fixed_index=bench.FIXED_INDEX)
@@ -38,11 +39,10 @@ elif what == "scan":
     fn = lambda: m._check(m.L.qpsk_timing_scan_batch(m.h, x.data_ptr(), F, idx.data_ptr(), None))
 else:
     fn = lambda: m.rx_batch_raw(x, F, sym, fr, ph)
-per = 200
 t0 = time.time()
 n = 0
 last = 0.0
-while time.time() - t0 < secs:
+while n == 0 or time.time() - t0 < secs:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(per):
