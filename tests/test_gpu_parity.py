@@ -989,6 +989,64 @@ def test_streams_cplx_vs_oracle(oracle, generic, L, S):
     assert (m.last_kernel() == "stream_block_kernel") == (generic == 2)
 
 
+@pytest.mark.parametrize("fs,L,S,fixed", [(12000.0, 1000, 3, None), (19200.0, 520, 2, None), (9600.0, 2048, 40, None), (9600.0, 1020, 2, None),
+                                          (19200.0, 512, 5, 3), (9600.0, 28, 4, None)])
+def test_stream_block_kernel_shapes(oracle, fs, L, S, fixed):
+    """the one-launch-per-block kernel on PCM streams block after block against the oracle's modem: CYCLES = 5 (a true division in
+    the scan), blocks that are not whole 512-sample tiles, 16-symbol groups or 16-byte rows of PCM, an odd length, more streams,
+    a block shorter than the filter, fixed timing; every block's index, symbols, costas_frame[], loop state"""
+    from oracle.pyoracle import TIMING_HIST
+    rs = 2400.0
+    mode = TIMING_FIXED if fixed is not None else TIMING_HIST
+    kw = dict(timing_mode=mode, fixed_index=fixed) if fixed is not None else dict(timing_mode=mode)
+    m = modem(fs=fs, rs=rs, frame_size=L, **kw)
+    m.tune(stream_block=1)
+    m.streams_reset(S, 1500.0)
+    om = [oracle.modem(fs, rs, L, loop_bw=BW, **kw) for _ in range(S)]
+    for o in om:
+        o.set_mixer_hz(1500.0)
+    rng = np.random.default_rng(int(fs) + L)
+    for k in range(5):
+        pcm = (5000 * rng.standard_normal((S, L))).astype(np.int16)
+        if k == 2:
+            pcm[0] = 0                                     # an all-zero block: index 1 (SURVEY Q4), zero symbols next block
+        o = m.streams_rx_pcm(pcm)
+        m.sync()
+        assert m.last_kernel() == "stream_block_kernel"
+        for s_ in range(S):
+            om[s_].rx_pcm(pcm[s_])
+            assert cpu(o["index"])[s_] == om[s_].index, (k, s_)
+            assert bits_equal(cpu(o["sym"][s_]), om[s_].symbols) and bits_equal(cpu(o["costas"][s_]), om[s_].costas_frame), (k, s_)
+            assert cpu(o["phase"])[s_] == om[s_].phase and cpu(o["freq"])[s_] == om[s_].freq, (k, s_)
+
+
+def test_stream_block_kernel_flags_bad_input(oracle):
+    """NaN PCM cannot exist (int16), but a complex block can carry one: the one-launch kernel flags the call like the batch kernels do
+    (QPSK_ERR_RANGE at the next synchronisation) and the context stays usable"""
+    import qpsk_amd
+    fs, rs, L, S = 19200.0, 2400.0, 1024, 3
+    m = modem(fs=fs, rs=rs, frame_size=L)
+    m.tune(stream_block=1)
+    m.streams_reset(S)
+    x, _ = make_frames(S, L * 3, 8, m.taps, fs, base_seed=2)
+    blk = np.ascontiguousarray(x[:, :L])
+    blk[1, 100, 0] = np.float32("nan")
+    m.streams_rx_cplx(blk)             # the NaN reaches stream 1's picks ...
+    m.sync()
+    m.streams_rx_cplx(np.ascontiguousarray(x[:, L:2 * L]))      # ... and its loop in the next block
+    with pytest.raises(qpsk_amd.QpskError, match="-6"):
+        m.sync()
+    m.streams_reset(S)
+    om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
+    for k in range(2):
+        b = np.ascontiguousarray(x[:, k * L:(k + 1) * L])
+        o = m.streams_rx_cplx(b)
+        m.sync()
+        for s_ in range(S):
+            om[s_].rx_cplx(b[s_])
+            assert bits_equal(cpu(o["sym"][s_]), om[s_].symbols)
+
+
 # ------------------------------------------------------------------ robustness of the product library
 def test_environment_cannot_change_results(oracle, monkeypatch):
     """the ablation bits of QPSK_PIPE_DBG (1: skip the filter arithmetic, 2: skip the recurrence) exist only in the

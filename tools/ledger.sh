@@ -5,6 +5,8 @@
 #     bash tools/ledger.sh       -> gpurun_out/ledger.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/ledger.txt
+# the measurement library is a build product that does not travel (.gpurunignore): build it here
+[ -f qpsk_amd/libqpsk_hip_prof.so ] || make -C qpsk_amd/csrc profile > gpurun_out/prof_build.log 2>&1
 {
 echo "== product kernels, measurement build (QPSK_PIPE_DBG: 1 no filter multiplies/adds, 16384 no window reads after the first two blocks, 32768 no flush arithmetic,"
 echo "   65536 no window staging writes, 2 no Costas recurrence; WRONG results by construction)"
