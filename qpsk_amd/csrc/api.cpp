@@ -67,6 +67,7 @@ struct Tuning {
     int pipe_variant = -1;                            /* pipeline kernel: layout bits (kernels.h, FusedArgs::dbg) */
     int hist_generic = -1;                            /* histogram estimate: 1 = rrc_fir + scan kernels (no fused scan), 2 = those with the generic scan */
     int fir_generic = -1;                             /* full-rate rrc_fir(): 1 = the compiler-scheduled rrc_fir_kernel also for symmetric taps */
+    int stream_scan = -1;                             /* streams from PCM, histogram timing: 1 = stream_scan_kernel (mixer + filter + scan) whatever the stream count, 0 = never */
     int stream_poll = -1;                             /* qpsk_streams_rx_pcm_host on the one-launch kernel: 0 = wait with hipStreamSynchronize instead of watching the kernel's counter */
     int stream_block = -1;                            /* streams: 0 = never the one-launch-per-block kernel (streamblock.hip), 1 = whenever the shape allows, unset: up to 1024 streams */
     int fft_fused = -1;                               /* FFT timing estimate: 0 = always a launch of its own (1 / unset: inside rx_fused_pipe_kernel's launch for full workgroups) */
@@ -80,6 +81,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
     {"QPSK_PIPE_LAYOUT_LO", &Tuning::layout_lo}, {"QPSK_PIPE_LAYOUT_HI", &Tuning::layout_hi},
     {"QPSK_FIR_GENERIC", &Tuning::fir_generic}, {"QPSK_FFT_FUSED", &Tuning::fft_fused},
     {"QPSK_STREAM_BLOCK", &Tuning::stream_block}, {"QPSK_STREAM_POLL", &Tuning::stream_poll},
+    {"QPSK_STREAM_SCAN", &Tuning::stream_scan},
 };
 
 /* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
@@ -256,6 +258,7 @@ int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stre
     KERNEL_TRY(prepare_pipe_kernel());
     KERNEL_TRY(prepare_timing_scan());
     KERNEL_TRY(prepare_stream_block());
+    KERNEL_TRY(prepare_stream_scan());
     qpsk_ctx *c = new qpsk_ctx();
     c->device = device;
     for (const auto &k : TUNING_KEYS) {   /* the only place the environment is read */
@@ -758,7 +761,7 @@ int qpsk_rx_batch_bw(qpsk_ctx *c, const float *d_in, int nframes, const float *h
  * block's picks once the loop has taken the old ones (qpsk.c:186-191). */
 static int costas_over_symbols(qpsk_ctx *c, float *d_symbols, int nframes, int nsym, int dstride, float *d_state,
                                uint8_t *d_sym, float *d_costas, const float *refill = nullptr,
-                               const int32_t *refill_index = nullptr)
+                               const int32_t *refill_index = nullptr, bool refill_planar = false)
 {
     if (tuned(c->tune.generic, 0)) {
         KERNEL_TRY(launch_costas(d_symbols, nframes, nsym, dstride, 1, c->d_gains, c->min_freq, c->max_freq, d_state, d_state,
@@ -776,6 +779,7 @@ static int costas_over_symbols(qpsk_ctx *c, float *d_symbols, int nframes, int n
     a.cycles = c->cycles;
     a.refill = reinterpret_cast<const float2 *>(refill);
     a.refill_dst = reinterpret_cast<float2 *>(d_symbols);
+    a.refill_planar = refill_planar ? 1 : 0;
     a.index = refill_index;
     a.gains = c->d_gains;
     a.nbw = 1;
@@ -1022,6 +1026,66 @@ static int streams_copy_loop(qpsk_ctx *c, float *d_freq, float *d_phase)
     return QPSK_OK;
 }
 
+/* A block of the running streams from the rrc_fir() call on (qpsk.c:125-212).  filtered: c->filtered already holds the filtered
+ * block and the delay lines are updated (mix_fir_kernel did both); otherwise d_in is the complex block to filter. */
+static int streams_from_filter(qpsk_ctx *c, const float *d_in, bool filtered, uint8_t *d_sym, float *d_freq, float *d_phase,
+                               float *d_costas, int32_t *d_index, bool scanned = false)
+{
+    const int n = c->nstreams, L = c->prm.frame_size, N = c->nsym;
+    int rc = ensure(c, c->filtered, sizeof(float) * 2 * (size_t)n * L);
+    if (rc) return rc;
+    rc = ensure(c, c->index, sizeof(int32_t) * (size_t)n);
+    if (rc) return rc;
+    float *filt = (float *)c->filtered.p;
+    int32_t *idx = (int32_t *)c->index.p;
+    if (!filtered) {
+        /* qpsk.c:125 */
+        KERNEL_TRY(fir_full_rate(c, d_in, c->s_memory, filt, n, L));
+        KERNEL_TRY(launch_delay_line(d_in, c->s_memory, n, L, c->stream));
+    }
+    /* qpsk.c:127-180 (scanned: stream_scan_kernel has left the index, and the filtered block planar by decimation phase) */
+    if (scanned) {
+    } else if (c->prm.timing_mode == QPSK_TIMING_HIST)
+        KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, nullptr, tuned(c->tune.hist_generic, 0) == 2, c->stream));
+    else if (c->prm.timing_mode == QPSK_TIMING_FIXED)
+        KERNEL_TRY(launch_fill_i32(idx, n, c->prm.fixed_index, c->stream));
+    else if (!d_in)
+        return fail(QPSK_ERR_STATE, "internal: the FFT timing estimate needs the unfiltered block");
+    else if (int rf = fft_timing_indices(c, d_in, n, idx))   /* stateless: it looks at the raw block from sample 2 on */
+        return rf;
+    /* qpsk.c:196-212 over decimated_frame[0..N) = the PREVIOUS block's picks, which s_dec holds; qpsk.c:186-191:
+     * this block's picks replace them for the next call */
+    if (int rg = use_context_gains(c)) return rg;
+    rc = costas_over_symbols(c, c->s_dec, n, N, N, c->s_loop, d_sym, d_costas, filt, idx, scanned);
+    if (rc) return rc;
+    if (d_index) HIP_TRY(hipMemcpyAsync(d_index, idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    return streams_copy_loop(c, d_freq, d_phase);
+}
+
+/* Many streams, histogram timing: mixer, filter and scan as ONE kernel (streamscan.hip) -- the carrier recurrences run a tile ahead
+ * of the filter waves of the same workgroup, PCM comes in at 2 bytes per sample, no mixed block goes through HBM and the scan
+ * reads the filtered samples from LDS.  A workgroup takes 16 streams through the whole block (its time does not shrink with the
+ * batch), so it pays from about 2500 streams on; below that the kernels apart are quicker. */
+static bool stream_scan_ok(const qpsk_ctx *c)
+{
+    return c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0 && tuned(c->tune.generic, 0) == 0 && c->cycles == 8 &&
+           c->prm.timing_mode == QPSK_TIMING_HIST && c->prm.frame_size % stream_scan_tile() == 0 &&
+           tuned(c->tune.stream_scan, c->nstreams >= 2560 ? 1 : 0) != 0;
+}
+
+static int streams_scanned(qpsk_ctx *c, const int16_t *d_pcm, const float *d_cplx, uint8_t *d_sym, float *d_freq, float *d_phase,
+                           float *d_costas, int32_t *d_index)
+{
+    const int n = c->nstreams, L = c->prm.frame_size;
+    int rf = ensure(c, c->filtered, sizeof(float) * 2 * (size_t)n * L);
+    if (rf) return rf;
+    rf = ensure(c, c->index, sizeof(int32_t) * (size_t)n);
+    if (rf) return rf;
+    KERNEL_TRY(launch_stream_scan(d_pcm, d_cplx, c->s_mixer, c->s_memory, (float *)c->filtered.p, c->d_taps, (int32_t *)c->index.p, n, L,
+                                  c->d_status, c->stream));
+    return streams_from_filter(c, nullptr, true, d_sym, d_freq, d_phase, d_costas, d_index, true);
+}
+
 int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *d_freq, float *d_phase,
                          float *d_costas, int32_t *d_index)
 {
@@ -1032,30 +1096,9 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
         if (int rb = streams_block_launch(c, nullptr, d_in, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
         return streams_copy_loop(c, d_freq, d_phase);
     }
-    const int n = c->nstreams, L = c->prm.frame_size, N = c->nsym;
-    int rc = ensure(c, c->filtered, sizeof(float) * 2 * (size_t)n * L);
-    if (rc) return rc;
-    rc = ensure(c, c->index, sizeof(int32_t) * (size_t)n);
-    if (rc) return rc;
-    float *filt = (float *)c->filtered.p;
-    int32_t *idx = (int32_t *)c->index.p;
-    /* qpsk.c:125 */
-    KERNEL_TRY(fir_full_rate(c, d_in, c->s_memory, filt, n, L));
-    KERNEL_TRY(launch_delay_line(d_in, c->s_memory, n, L, c->stream));
-    /* qpsk.c:127-180 */
-    if (c->prm.timing_mode == QPSK_TIMING_HIST)
-        KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, nullptr, tuned(c->tune.hist_generic, 0) == 2, c->stream));
-    else if (c->prm.timing_mode == QPSK_TIMING_FIXED)
-        KERNEL_TRY(launch_fill_i32(idx, n, c->prm.fixed_index, c->stream));
-    else if (int rf = fft_timing_indices(c, d_in, n, idx))   /* stateless: it looks at the raw block from sample 2 on */
-        return rf;
-    /* qpsk.c:196-212 over decimated_frame[0..N) = the PREVIOUS block's picks, which s_dec holds; qpsk.c:186-191:
-     * this block's picks replace them for the next call */
-    if (int rg = use_context_gains(c)) return rg;
-    rc = costas_over_symbols(c, c->s_dec, n, N, N, c->s_loop, d_sym, d_costas, filt, idx);
-    if (rc) return rc;
-    if (d_index) HIP_TRY(hipMemcpyAsync(d_index, idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-    return streams_copy_loop(c, d_freq, d_phase);
+    if (stream_scan_ok(c) && ((uintptr_t)d_in % 16) == 0)
+        return streams_scanned(c, nullptr, d_in, d_sym, d_freq, d_phase, d_costas, d_index);
+    return streams_from_filter(c, d_in, false, d_sym, d_freq, d_phase, d_costas, d_index);
 }
 
 int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float *d_freq, float *d_phase,
@@ -1069,6 +1112,8 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
         return streams_copy_loop(c, d_freq, d_phase);
     }
     const int n = c->nstreams, L = c->prm.frame_size;
+    if (stream_scan_ok(c) && ((uintptr_t)d_pcm % 4) == 0)
+        return streams_scanned(c, d_pcm, nullptr, d_sym, d_freq, d_phase, d_costas, d_index);
     int rc = ensure(c, c->mixed, sizeof(float) * 2 * (size_t)n * L);
     if (rc) return rc;
     /* qpsk.c:114-120 */

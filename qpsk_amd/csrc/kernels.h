@@ -46,6 +46,7 @@ struct FusedArgs {
      * refill rows are frame_size samples apart.  NULL = leave dsrc alone */
     const float2 *refill;
     float2 *refill_dst;     /* = dsrc, writable */
+    int refill_planar;      /* refill rows are [cycles][nsym] planes (phase-major: what stream_scan_kernel leaves) instead of frame_size samples */
     const float *taps;      /* [127] */
     const float *gains;     /* [nbw][2] alpha, beta */
     int nbw;
@@ -158,6 +159,12 @@ int stream_block_max_frame(void);
 int prepare_stream_block(void);
 int launch_stream_block(const StreamBlockArgs &a, int nstreams, hipStream_t s, const StreamBlockInline *inl = nullptr);   /* inl: PCM and, if
                         a.loop_in is set (to anything), the loop state come from *inl instead of a.pcm / a.loop_in */
+/* streamscan.hip: PCM -> mix -> rrc_fir() -> histogram timing of running streams in one kernel (CYCLES = 8, frame_size %
+ * stream_scan_tile() == 0, symmetric taps); yout [n][8][frame_size / 8] planar by decimation phase; updates mixer [n][4], memory [n][127] */
+int stream_scan_tile(void);
+int prepare_stream_scan(void);
+int launch_stream_scan(const int16_t *pcm, const float *x, float *mixer, float *memory, float *yout, const float *taps, int32_t *index,
+                       int nstreams, int frame_size, int *status, hipStream_t s);   /* exactly one of pcm / x (complex blocks: no mixer) */
 /* bitstages.hip */
 int launch_crc16(const uint8_t *data, int npackets, int nbytes, uint16_t *crc, hipStream_t s);
 int launch_interleave(uint8_t *data, int npackets, int nbytes, unsigned b, int dir, hipStream_t s);

@@ -539,7 +539,10 @@ costas_pipe_kernel(FusedArgs a, int *status)
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int i = c * S + R * q + r, s = i * a.cycles + ix;
-                if (i < N) row[i] = s < a.frame_size ? blk[s] : make_float2(0.0f, 0.0f);
+                if (i < N) {
+                    if (a.refill_planar) row[i] = blk[(size_t)ix * N + i];      /* the block planar by decimation phase (streamscan.hip): [phase][symbol] */
+                    else row[i] = s < a.frame_size ? blk[s] : make_float2(0.0f, 0.0f);
+                }
             }
         }
     }

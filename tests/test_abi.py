@@ -149,7 +149,7 @@ int main(void)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("block", [1, 0])
+@pytest.mark.parametrize("block", [1, 0, 2])
 def test_streams_rx_pcm_host_equals_the_device_pointer_calls(oracle, block):
     """qpsk_streams_rx_pcm_host (one upload, one download, one synchronisation per block: what the drop-in rx_frame()
     runs on) gives the bits of the oracle's modem block after block, loop state in and out included"""
@@ -158,7 +158,8 @@ def test_streams_rx_pcm_host_equals_the_device_pointer_calls(oracle, block):
     from sigutil import bits_equal
     fs, rs, L, S, B = 9600.0, 2400.0, 512, 3, 6
     m = qpsk_amd.Modem(fs=fs, rs=rs, frame_size=L)
-    m.tune(stream_block=block)      # 1: one launch per block reading and writing the pinned staging buffer; 0: copies + five kernels
+    m.tune(stream_block=1 if block == 1 else 0)      # 1: one launch per block on the pinned staging buffer; 0: copies + the composition
+    m.tune(stream_scan=1 if block == 2 else 0)       # 2: mixer + filter + scan as one kernel (needs whole 256-sample tiles at CYCLES = 8)
     m.streams_reset(S, 1500.0)
     rng = np.random.default_rng(3)
     om = [oracle.modem(fs, rs, L, loop_bw=np.float32(2.0 * 3.14159265358979323846 / 100.0)) for _ in range(S)]

@@ -923,15 +923,17 @@ def test_tx_requires_reset():
 
 
 # ------------------------------------------------------------------ streams (consecutive rx_frame calls)
-@pytest.mark.parametrize("block", [1, 0])
+@pytest.mark.parametrize("block", [1, 0, 2])
 @pytest.mark.parametrize("name", ["shipped", "c1small"])
 def test_streams_pcm_golden(name, block):
     """consecutive rx_frame() calls against the reference's recordings: block = 1 the one-launch-per-block kernel
-    (streamblock.hip: what few short streams get), 0 the five-kernel composition"""
+    (streamblock.hip: what few short streams get), 0 the composition for few / long streams (mixer, filter, scan and loop kernels),
+    2 mixer + filter + scan as one kernel (streamscan.hip: what thousands of streams get; needs whole 256-sample tiles at CYCLES = 8)"""
     g = golden("stream_pcm_%s.npz" % name)
     L = int(g["frame_size"])
     m = modem(fs=float(g["fs"]), rs=float(g["rs"]), frame_size=L, loop_bw=np.float32(g["loop_bw"]))
-    m.tune(stream_block=block)
+    m.tune(stream_block=1 if block == 1 else 0)
+    m.tune(stream_scan=1 if block == 2 else 0)
     m.streams_reset(3, 1500.0)
     for k in range(g["sym"].shape[0]):
         blk = np.repeat(g["pcm"][k * L:(k + 1) * L][None], 3, 0)
@@ -941,7 +943,7 @@ def test_streams_pcm_golden(name, block):
             assert cpu(o["index"])[s] == g["index"][k]
             assert bits_equal(cpu(o["sym"][s]), g["sym"][k]) and bits_equal(cpu(o["costas"][s]), g["costas"][k])
             assert cpu(o["phase"])[s] == g["phase"][k] and cpu(o["freq"])[s] == g["freq"][k]
-    assert (m.last_kernel() == "stream_block_kernel") == bool(block)
+    assert (m.last_kernel() == "stream_block_kernel") == (block == 1)
 
 
 def test_streams_with_fft_timing(oracle):
@@ -964,16 +966,19 @@ def test_streams_with_fft_timing(oracle):
             assert cpu(o["phase"])[s] == om[s].phase and cpu(o["freq"])[s] == om[s].freq
 
 
-@pytest.mark.parametrize("generic,L,S", [(0, 1024, 9), (1, 1024, 9), (2, 1024, 9), (2, 2048, 70), (2, 1000, 3), (0, 4096, 5)])
+@pytest.mark.parametrize("generic,L,S", [(0, 1024, 9), (1, 1024, 9), (2, 1024, 9), (2, 2048, 70), (2, 1000, 3), (0, 4096, 5), (4, 1024, 9),
+                                         (4, 2048, 40), (4, 256, 17)])
 def test_streams_cplx_vs_oracle(oracle, generic, L, S):
     """generic = 1: the barrier-synchronised kernels (decimate_kernel + costas_kernel) instead of the pipeline; 0: the
-    five-kernel composition with the pipeline kernel; 2: the one-launch-per-block kernel (the library's own choice for few
-    short streams), also with a frame that is not whole 512-sample tiles or whole 16-symbol groups"""
+    composition of filter, scan and loop kernels; 2: the one-launch-per-block kernel (the library's own choice for few short
+    streams), also with a frame that is not whole 512-sample tiles or whole 16-symbol groups; 4: filter + scan as one kernel with the
+    filtered block left planar for the loop kernel's picks (streamscan.hip, complex input: what thousands of streams get)"""
     fs, rs = 19200.0, 2400.0
     m = modem(fs=fs, rs=rs, frame_size=L)
     if generic == 1:
         m.tune(fused_generic=1)
     m.tune(stream_block=1 if generic == 2 else 0)
+    m.tune(stream_scan=1 if generic == 4 else 0)
     m.streams_reset(S)
     om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
     x, _ = make_frames(S, L * 5, 8, m.taps, fs, offset_hz=30.0, base_seed=17, noise=0.02)
@@ -1018,6 +1023,38 @@ def test_stream_block_kernel_shapes(oracle, fs, L, S, fixed):
             assert cpu(o["index"])[s_] == om[s_].index, (k, s_)
             assert bits_equal(cpu(o["sym"][s_]), om[s_].symbols) and bits_equal(cpu(o["costas"][s_]), om[s_].costas_frame), (k, s_)
             assert cpu(o["phase"])[s_] == om[s_].phase and cpu(o["freq"])[s_] == om[s_].freq, (k, s_)
+
+
+@pytest.mark.parametrize("L,S", [(2048, 47), (256, 33), (1024, 16), (4096, 5)])
+def test_streams_pcm_mixer_filter_and_scan_in_one_kernel(oracle, L, S):
+    """stream_scan_kernel (PCM in; the carrier recurrences of a workgroup's 16 streams a tile ahead of its filter waves, the scan fed
+    from LDS, the filtered block left planar by decimation phase for the loop kernel's picks) block after block against the oracle's
+    modems: several workgroups and a ragged last one, one to sixteen tiles per block, state carried through five blocks (delay
+    lines, carrier phase, loop, picks), an all-zero block; and equal to the four kernels apart bit for bit"""
+    fs, rs = 19200.0, 2400.0
+    m = modem(fs=fs, rs=rs, frame_size=L)
+    m2 = modem(fs=fs, rs=rs, frame_size=L)
+    for mm, scan in ((m, 1), (m2, 0)):
+        mm.tune(stream_block=0)
+        mm.tune(stream_scan=scan)
+        mm.streams_reset(S, 1500.0)
+    om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
+    for o in om:
+        o.set_mixer_hz(1500.0)
+    rng = np.random.default_rng(L + S)
+    for k in range(5):
+        pcm = (6000 * rng.standard_normal((S, L))).astype(np.int16)
+        if k == 3:
+            pcm[1] = 0
+        o1, o2 = m.streams_rx_pcm(pcm), m2.streams_rx_pcm(pcm)
+        m.sync(); m2.sync()
+        for key in ("sym", "costas", "phase", "freq", "index"):
+            assert bits_equal(cpu(o1[key]), cpu(o2[key])), (k, key)
+        for s_ in sorted(set((0, 1, S // 2, S - 2, S - 1))):
+            om[s_].rx_pcm(pcm[s_])
+            assert cpu(o1["index"])[s_] == om[s_].index, (k, s_)
+            assert bits_equal(cpu(o1["sym"][s_]), om[s_].symbols) and bits_equal(cpu(o1["costas"][s_]), om[s_].costas_frame), (k, s_)
+            assert cpu(o1["phase"])[s_] == om[s_].phase and cpu(o1["freq"])[s_] == om[s_].freq, (k, s_)
 
 
 def test_stream_block_kernel_flags_bad_input(oracle):
