@@ -1066,11 +1066,14 @@ static int streams_from_filter(qpsk_ctx *c, const float *d_in, bool filtered, ui
  * of the filter waves of the same workgroup, PCM comes in at 2 bytes per sample, no mixed block goes through HBM and the scan
  * reads the filtered samples from LDS.  A workgroup takes 16 streams through the whole block (its time does not shrink with the
  * batch), so it pays from about 2500 streams on; below that the kernels apart are quicker. */
-static bool stream_scan_ok(const qpsk_ctx *c)
+static bool stream_scan_ok(const qpsk_ctx *c, bool pcm)
 {
+    /* [measured, profiles/r04_streams_blocks.txt] 2560 streams: PCM input 0.94 against 1.03 ms per block with the kernels apart, complex
+     * input 0.79 against 0.70; 4096 streams: 1.00 against 1.27 and 0.92 against 1.01 */
+    const int from = pcm ? 2560 : 3584;
     return c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0 && tuned(c->tune.generic, 0) == 0 && c->cycles == 8 &&
            c->prm.timing_mode == QPSK_TIMING_HIST && c->prm.frame_size % stream_scan_tile() == 0 &&
-           tuned(c->tune.stream_scan, c->nstreams >= 2560 ? 1 : 0) != 0;
+           tuned(c->tune.stream_scan, c->nstreams >= from ? 1 : 0) != 0;
 }
 
 static int streams_scanned(qpsk_ctx *c, const int16_t *d_pcm, const float *d_cplx, uint8_t *d_sym, float *d_freq, float *d_phase,
@@ -1096,7 +1099,7 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
         if (int rb = streams_block_launch(c, nullptr, d_in, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
         return streams_copy_loop(c, d_freq, d_phase);
     }
-    if (stream_scan_ok(c) && ((uintptr_t)d_in % 16) == 0)
+    if (stream_scan_ok(c, false) && ((uintptr_t)d_in % 16) == 0)
         return streams_scanned(c, nullptr, d_in, d_sym, d_freq, d_phase, d_costas, d_index);
     return streams_from_filter(c, d_in, false, d_sym, d_freq, d_phase, d_costas, d_index);
 }
@@ -1112,7 +1115,7 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
         return streams_copy_loop(c, d_freq, d_phase);
     }
     const int n = c->nstreams, L = c->prm.frame_size;
-    if (stream_scan_ok(c) && ((uintptr_t)d_pcm % 4) == 0)
+    if (stream_scan_ok(c, true) && ((uintptr_t)d_pcm % 4) == 0)
         return streams_scanned(c, d_pcm, nullptr, d_sym, d_freq, d_phase, d_costas, d_index);
     int rc = ensure(c, c->mixed, sizeof(float) * 2 * (size_t)n * L);
     if (rc) return rc;

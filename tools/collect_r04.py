@@ -136,6 +136,16 @@ def main():
     text("fir_fast", "fir", "qpsk_rrc_fir_batch on the config-2 block, 4096 x 16384 samples (tools/bench_fir_fast.py): per-launch event times (clocks not settled: see r04_power.txt for steady state).")
     text("dropin", "dropin_rx_frame", "The drop-in rx_frame() (examples/dropin_main.c through libqpsk_hip) against the reference's rx_frame() compiled here (tools/bench_dropin.py 3000).")
     text("config5", "config5", "BASELINE config 5 (tools/bench_config5.py).")
+    blocks = []
+    for name, label in (("streams", "4096 streams, the library's choice (mixer + filter + scan as one kernel)"), ("streams_apart", "4096 streams, QPSK_STREAM_SCAN=0 (mixer, filter, scan kernels apart)"),
+                        ("streams_2560", "2560 streams, the library's choice"), ("streams_2560_apart", "2560 streams, QPSK_STREAM_SCAN=0")):
+        p = os.path.join(SRC, name + ".log")
+        if ok(name) and os.path.exists(p):
+            blocks += [label + ":"] + ["  " + ln for ln in open(p).read().splitlines() if ln.startswith("streams")]
+    if blocks:
+        open(os.path.join(OUT, "%s_streams_blocks.txt" % TAG), "w").write(
+            "Streaming mode, 16384-sample blocks, histogram timing: ms per block of all streams, one call per block with an event pair and a synchronisation around it\n"
+            "(tools/bench_streams.py; median of blocks 2-6 after qpsk_streams_reset):\n\n" + "\n".join(blocks) + "\n")
     hosts = []
     for n in (1, 8, 64):
         p = os.path.join(SRC, "streams_host_%d.log" % n)
@@ -160,7 +170,7 @@ def main():
                "kernels in order, complex input first (6 blocks), then PCM input (6 blocks).", ""]
         for r in rows:
             n = r["Kernel_Name"].split("(")[0].replace("qpsk::", "").replace("void ", "")
-            if n.split("<")[0] in ("costas_pipe_kernel", "rrc_fir_kernel", "rrc_fir_stream_kernel", "mixer_kernel", "timing_hist8_kernel", "stream_block_kernel"):
+            if n.split("<")[0] in ("costas_pipe_kernel", "rrc_fir_kernel", "rrc_fir_stream_kernel", "mixer_kernel", "timing_hist8_kernel", "stream_block_kernel", "stream_scan_kernel"):
                 out.append("%-26s start %9.1f us   %8.1f us" % (n, (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
         open(os.path.join(OUT, "%s_streams_per_call.txt" % TAG), "w").write("\n".join(out) + "\n")
     print(len(glob.glob(os.path.join(OUT, TAG + "_*"))), "files under profiles/%s_*" % TAG)

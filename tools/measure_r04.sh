@@ -49,6 +49,13 @@ if [[ $part == *c* ]]; then
 run bench_torchrun4_shared python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 4 --frames 1024 --cpu-frames 0
 make -C qpsk_amd/csrc VARIANT=sbprof EXTRA=-DQPSK_SBLK_PROF > $O/sbprof_build.log 2>&1 && QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_sbprof.so txt stream_block_profile python3 tools/bench_streams_host.py 1 60
 fi
+if [[ $part == *d* ]]; then      # the streams composition alone (after streamscan.hip)
+prof prof_streams python3 tools/bench_streams.py
+txt streams python3 tools/bench_streams.py
+QPSK_STREAM_SCAN=0 txt streams_apart python3 tools/bench_streams.py
+txt streams_2560 python3 tools/bench_streams.py --streams 2560
+QPSK_STREAM_SCAN=0 txt streams_2560_apart python3 tools/bench_streams.py --streams 2560
+fi
 # what travels back is capped at 64 MiB: keep the summaries, drop the per-launch traces except the streams' (per-call table) and rocprofv3's databases
 find $O -name "*kernel_trace.csv" ! -path "*prof_streams*" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*.db" -delete; du -sh $O | tail -1
 ls $O/*.failed 2>/dev/null; cut -c1-300 $O/bench.json 2>/dev/null
