@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-shard", action="store_true",
                     help="N = 1, config 2 only: skip the extra measurement of the 8192-frame per-GPU share (key shard_8192)")
+    ap.add_argument("--no-streams", action="store_true",
+                    help="N = 1, config 2 only: skip the extra measurements of the streaming mode (4096 running PCM streams per block; one rx_frame() block per call)")
     ap.add_argument("--no-timing-modes", action="store_true",
                     help="N = 1, config 2 only: skip the extra measurements of the same batch with the FFT timing estimate in front "
                          "(BASELINE configs[2], key config3) and with the reference's histogram estimate (key hist)")
@@ -469,6 +471,69 @@ def main():
             want = Oracle().rx_batch(xh, FS, RS, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX)
             sh["symbol_mismatches_64_frames"] = int(np.sum(outs2[0][:64].cpu().numpy() != want["sym"]))
         res["shard_8192"] = sh
+    if world == 1 and (args.frames, L) == (FRAMES_1GPU, 16384) and not args.no_streams:
+        # SURVEY 8(f) N1, the reference's real input and call pattern (qpsk.c:88, 344-354), measured beside the headline and NOT part of it:
+        #  (a) 4096 running streams, one 16384-sample int16 PCM block each per call (PCM from the library's own transmit chain at +50 Hz):
+        #      mixer + rrc_fir() + histogram timing in one kernel, then the loop kernel; ms per block = median of blocks 2..7, an event pair
+        #      and a synchronisation around every call;
+        #  (b) ONE stream, one 512-sample block per call through host buffers (the shipped FS 9600 / RS 2400 / FRAME_SIZE 512): the
+        #      drop-in rx_frame()'s path, wall time per call.
+        import ctypes as C_
+        S_ = 4096
+        ms_ = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_HIST, device=local)
+        ms_.streams_reset(S_, 1500.0)
+        mtx = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, device=local)
+        mtx.tx_reset(S_, 1550.0)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(77)
+        nblk, tms, pcm_blocks = 8, [], []
+        o_last = None
+        for k in range(nblk):
+            symk = torch.randint(0, 4, (S_, L // CYCLES), generator=gen, device=dev, dtype=torch.uint8)
+            pcmk = mtx.tx_symbols(symk, want_pcm=True)["pcm"]
+            mtx.sync()
+            if k < 3:
+                pcm_blocks.append(pcmk[0].cpu().numpy())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o_ = ms_.streams_rx_pcm(pcmk, want_costas=False)
+            e1.record()
+            torch.cuda.synchronize()
+            tms.append(e0.elapsed_time(e1))
+            if k == 2:
+                o_last = {kk: vv[0].cpu().numpy() for kk, vv in o_.items() if vv is not None}
+        ms_.sync()
+        st = {"streams": S_, "block_samples": L, "timing": "histogram (qpsk.c:127-180)", "kernels": "stream_scan_kernel + costas_pipe_kernel",
+              "pcm_block_ms": float(np.median(tms[2:])), "pcm_msamples_per_s": S_ * L / (float(np.median(tms[2:])) * 1e-3) / 1e6,
+              "first_blocks_ms": [float(t) for t in tms[:2]]}
+        if not args.no_parity:      # stream 0, blocks 0..2, against the oracle's modem (state carried)
+            from oracle.pyoracle import Oracle, TIMING_HIST
+            om = Oracle().modem(FS, RS, L, timing_mode=TIMING_HIST)
+            om.set_mixer_hz(1500.0)
+            for blk in pcm_blocks:
+                om.rx_pcm(blk)
+            st["stream0_block2_symbol_mismatches"] = int(np.sum(o_last["sym"] != om.symbols))
+            st["stream0_block2_index_ok"] = bool(int(o_last["index"]) == int(om.index))
+            st["stream0_block2_loop_bits_ok"] = bool(np.float32(o_last["phase"]) == np.float32(om.phase) and np.float32(o_last["freq"]) == np.float32(om.freq))
+        ms_.close(); mtx.close()
+        m1 = qpsk_amd.Modem(fs=9600.0, rs=2400.0, frame_size=512, device=local)
+        m1.streams_reset(1, 1500.0)
+        rng = np.random.default_rng(1)
+        nb = 2000
+        pc = (3000 * rng.standard_normal((nb, 512))).astype(np.int16)
+        lst = np.zeros((1, 2), np.float32); sy = np.zeros((1, m1.nsym), np.uint8); cs = np.zeros((1, m1.nsym, 2), np.float32); ix = np.zeros(1, np.int32)
+        ptrs = [C_.c_void_p(pc[k].ctypes.data) for k in range(nb)]
+        a_ = (C_.c_void_p(lst.ctypes.data), C_.c_void_p(sy.ctypes.data), C_.c_void_p(cs.ctypes.data), C_.c_void_p(ix.ctypes.data))
+        for k in range(100):
+            m1.L.qpsk_streams_rx_pcm_host(m1.h, ptrs[k], *a_)
+        t0 = time.perf_counter()
+        for k in range(nb):
+            m1.L.qpsk_streams_rx_pcm_host(m1.h, ptrs[k], *a_)
+        st["rx_frame_block_us"] = (time.perf_counter() - t0) / nb * 1e6
+        st["rx_frame_msamples_per_s"] = 512.0 / st["rx_frame_block_us"]
+        st["rx_frame_kernel"] = m1.last_kernel()
+        m1.close()
+        res["streams"] = st
     print(json.dumps(res), file=real_stdout, flush=True)
     if dist:
         dist.barrier()
