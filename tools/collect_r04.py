@@ -83,7 +83,7 @@ def main():
              "median over the launches of a pass; reads = FETCH_SIZE x 2 x 1024 B (gfx950 counts a 128-byte request of a 16-byte-per-lane streaming read as 64 B,",
              "MI355X_MICROARCH.md), writes = WRITE_SIZE x 1024 B).  Algorithmic bytes of a 4096 x 16384 batch: 536,870,912 (8 B per input sample).", ""]
     shapes = {}
-    for w, frames in (("config2", 4096), ("8192", 8192), ("config3", 4096), ("hist", 4096), ("fft_est", 4096), ("scan", 4096), ("fir", 4096)):
+    for w, frames in (("config2", 4096), ("8192", 8192), ("config3", 4096), ("hist", 4096), ("fft_est", 4096), ("scan", 4096), ("fir", 4096), ("streams", 4096)):
         fc, wc = counters("pmc_fetch_" + w), counters("pmc_write_" + w)
         for k in sorted(set(fc) | set(wc)):
             fv, wv = fc.get(k, {}).get("FETCH_SIZE"), wc.get(k, {}).get("WRITE_SIZE")
@@ -132,6 +132,8 @@ def main():
             open(os.path.join(OUT, "%s_%s.txt" % (TAG, dst)), "w").write(header + "\n\n" + "\n".join(body) + "\n")
     text("power", "power", "Board power, shader clock, per-XCD clocks and PPT throttle activity while one library call runs back to back for 6 s\n"
          "(tools/power_probe.py --cmd \"python3 tools/loop_kernel.py <workload> 6 [frames]\"; steady-state ms per call printed by the child).")
+    text("power_streams", "power_streams", "4096 running PCM streams, one 16384-sample block per call (qpsk_streams_rx_pcm: stream_scan_kernel + costas_pipe_kernel), back to back for 6 s\n"
+         "(tools/power_probe.py --cmd \"python3 tools/loop_kernel.py streams 6\").")
     text("config3", "config3", "BASELINE config 3 against config 2 in one process (tools/bench_config3.py --hist): K back-to-back qpsk_rx_batch calls between two events.")
     text("fir_fast", "fir", "qpsk_rrc_fir_batch on the config-2 block, 4096 x 16384 samples (tools/bench_fir_fast.py): per-launch event times (clocks not settled: see r04_power.txt for steady state).")
     text("dropin", "dropin_rx_frame", "The drop-in rx_frame() (examples/dropin_main.c through libqpsk_hip) against the reference's rx_frame() compiled here (tools/bench_dropin.py 3000).")

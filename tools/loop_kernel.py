@@ -5,6 +5,7 @@
     what: fir (qpsk_rrc_fir_batch, the stream kernel)   fir_generic (the compiler-scheduled rrc_fir_kernel)
           fft_est (qpsk_timing_fft_bin_batch)           scan (qpsk_timing_scan_batch)
           config2 / config3 / hist (qpsk_rx_batch in the three timing modes)
+          streams (qpsk_streams_rx_pcm: one 16384-sample PCM block of `frames` running streams per call, histogram timing)
 """
 import os
 import sys
@@ -21,7 +22,7 @@ secs = float(sys.argv[2]) if len(sys.argv) > 2 else 6.0
 F = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 per = int(sys.argv[4]) if len(sys.argv) > 4 else 200      # launches between two synchronisations (counter passes: a handful, with secs = 0)
 dev = torch.device("cuda", 0)
-mode = {"config3": qpsk_amd.TIMING_FFT, "fft_est": qpsk_amd.TIMING_FFT, "hist": qpsk_amd.TIMING_HIST}.get(what, qpsk_amd.TIMING_FIXED)
+mode = {"config3": qpsk_amd.TIMING_FFT, "fft_est": qpsk_amd.TIMING_FFT, "hist": qpsk_amd.TIMING_HIST, "streams": qpsk_amd.TIMING_HIST}.get(what, qpsk_amd.TIMING_FIXED)
 m = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=mode, fixed_index=bench.FIXED_INDEX)
 if what == "fir_generic":
     m.tune(fir_generic=1)
@@ -37,6 +38,10 @@ elif what == "fft_est":
     fn = lambda: m._check(m.L.qpsk_timing_fft_bin_batch(m.h, x.data_ptr(), F, idx.data_ptr(), None, None))
 elif what == "scan":
     fn = lambda: m._check(m.L.qpsk_timing_scan_batch(m.h, x.data_ptr(), F, idx.data_ptr(), None))
+elif what == "streams":
+    m.streams_reset(F, 1500.0)
+    pcm = (x[:, :, 0] * 8000.0).clamp(-32767, 32767).to(torch.int16).contiguous()
+    fn = lambda: m._check(m.L.qpsk_streams_rx_pcm(m.h, pcm.data_ptr(), sym.data_ptr(), fr.data_ptr(), ph.data_ptr(), None, idx.data_ptr()))
 else:
     fn = lambda: m.rx_batch_raw(x, F, sym, fr, ph)
 t0 = time.time()

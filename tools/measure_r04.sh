@@ -56,6 +56,14 @@ QPSK_STREAM_SCAN=0 txt streams_apart python3 tools/bench_streams.py
 txt streams_2560 python3 tools/bench_streams.py --streams 2560
 QPSK_STREAM_SCAN=0 txt streams_2560_apart python3 tools/bench_streams.py --streams 2560
 fi
+if [[ $part == *e* ]]; then      # final refresh: the bench lines (with the streams key) and the streams path's counters and power
+run bench python3 bench.py
+run bench20 python3 bench.py --steps 20 --warmup 5
+prof prof_bench python3 bench.py --cpu-frames 0
+pmcrun pmc_fetch_streams FETCH_SIZE python3 tools/loop_kernel.py streams 0 4096 8
+pmcrun pmc_write_streams WRITE_SIZE python3 tools/loop_kernel.py streams 0 4096 8
+txt power_streams python3 tools/power_probe.py --cmd "python3 tools/loop_kernel.py streams 6"
+fi
 # what travels back is capped at 64 MiB: keep the summaries, drop the per-launch traces except the streams' (per-call table) and rocprofv3's databases
 find $O -name "*kernel_trace.csv" ! -path "*prof_streams*" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*.db" -delete; du -sh $O | tail -1
 ls $O/*.failed 2>/dev/null; cut -c1-300 $O/bench.json 2>/dev/null
