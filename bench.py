@@ -452,6 +452,35 @@ def main():
             res[key] = ent
             mt.close()
             del outs_t, idx_t
+    if world == 1 and (F, L) == (FRAMES_1GPU, 16384) and not args.no_timing_modes:
+        # SURVEY 8(d)'s optional AWGN variant, reported separately (the reference has no channel model: qpsk.c:314-334): config 2's
+        # batch plus complex white noise at Es/N0 = 12 dB after the matched filter (sigma per component from the measured mean sample
+        # power), same kernel, same fixed offset.  The time is data-independent except through the loop's 2 pi wraps.
+        ga = torch.Generator(device=dev)
+        ga.manual_seed(4242)
+        psig = float((x[:64].double() ** 2).sum(dim=2).mean().item())            # mean |sample|^2 (8 samples per symbol)
+        esn0_db = 12.0
+        sigma = (psig * CYCLES / (10.0 ** (esn0_db / 10.0)) / 2.0) ** 0.5        # Es = 8 x mean sample power; N0 / 2 per component
+        xn = x.clone()
+        for f0_ in range(0, F, 512):
+            xn[f0_:f0_ + 512] += sigma * torch.randn(xn[f0_:f0_ + 512].shape, generator=ga, device=dev, dtype=torch.float32)
+        outs_n = (torch.empty_like(sym), torch.empty_like(freq), torch.empty_like(phase))
+        steps_n = max(args.steps, 100)
+        dtn, kmsn = timed_region(m, xn, F, outs_n, steps_n, max(1, args.warmup), args.settle)
+        hz_n = outs_n[1].double() * RS / (2 * np.pi)
+        aw = {"workload": "config 2's batch + complex AWGN, Es/N0 = %.0f dB (sigma %.4f per component), fixed timing offset" % (esn0_db, sigma),
+              "kernel": m.last_kernel(), "steps": steps_n, "ms_per_step": dtn / steps_n * 1e3, "step_ms_events": kmsn,
+              "frac_of_hbm_peak_on_8B_per_sample": BYTES_PER_SAMPLE * F * L / (kmsn * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              "mean_freq_hz": float(hz_n.mean().item()), "freq_hz_std": float(hz_n.std().item()),
+              "frames_within_2hz_of_50": int(((hz_n - 50.0).abs() < 2.0).sum().item())}
+        if not args.no_parity:
+            from oracle.pyoracle import Oracle, TIMING_FIXED
+            want_n = Oracle().rx_batch(xn[:32].cpu().numpy(), FS, RS, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX)
+            aw["parity_frames_checked"] = 32
+            aw["symbol_mismatches"] = int(np.sum(outs_n[0][:32].cpu().numpy() != want_n["sym"]))
+            aw["freq_bit_mismatches"] = int(np.sum(outs_n[1][:32].cpu().numpy().view(np.uint32) != want_n["freq"].view(np.uint32)))
+        res["awgn"] = aw
+        del xn, outs_n
     if world == 1 and (F, L) == (FRAMES_1GPU, 16384) and not args.no_shard:
         # BASELINE configs[3]'s per-GPU share (8192 x 16384: the shape of every rank of an N > 1 run, and the one where
         # the filter, not the recurrence, is the limit) measured in the same run, after config 2's region and by the

@@ -36,7 +36,7 @@ def test_bench_json_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2
     assert d["ranks"] == 1 and d["gpu_shared"] is False and len(d["devices"]) == 1 and d["devices"][0]["rank"] == 0
-    assert "shard_8192" not in d and "config3" not in d and "hist" not in d and "streams" not in d        # only beside config 2 itself (4096 x 16384), see test_bench_shard_key below
+    assert "shard_8192" not in d and "config3" not in d and "hist" not in d and "streams" not in d and "awgn" not in d        # only beside config 2 itself (4096 x 16384), see test_bench_shard_key below
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["unit"] == "Msamples/s" and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -76,7 +76,7 @@ def test_bench_shard_key_is_wired_to_config_2():
     code), without touching `value` / `config` / `roofline`"""
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'res["shard_8192"] = sh' in src and "(F, L) == (FRAMES_1GPU, 16384) and not args.no_shard" in src
-    assert src.count("timed_region(") == 4          # the definition and its uses: config 2, the timing modes, the shard
+    assert src.count("timed_region(") == 5          # the definition and its uses: config 2, the timing modes, the AWGN variant, the shard
     # BASELINE configs[2] (FFT timing estimate in front) and the reference's histogram mode ride along the same way
     assert 'res[key] = ent' in src and '("config3", qpsk_amd.TIMING_FFT' in src and '("hist", qpsk_amd.TIMING_HIST' in src
 
