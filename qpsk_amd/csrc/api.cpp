@@ -1059,6 +1059,8 @@ static int streams_from_filter(qpsk_ctx *c, const float *d_in, bool filtered, ui
     rc = costas_over_symbols(c, c->s_dec, n, N, N, c->s_loop, d_sym, d_costas, filt, idx, scanned);
     if (rc) return rc;
     if (d_index) HIP_TRY(hipMemcpyAsync(d_index, idx, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    c->last_kernel = scanned ? "stream_scan_kernel + costas_pipe_kernel"
+                             : tuned(c->tune.generic, 0) ? "filter, timing, costas_kernel, decimate_kernel" : "filter, timing, costas_pipe_kernel";
     return streams_copy_loop(c, d_freq, d_phase);
 }
 

@@ -43,6 +43,11 @@
  * too); the caller redoes that group with costas_step_t() and continues:
  *     min(|T.x|, |T.y|) == 0   (the detector's sgn(0) = -1 asymmetry, see costas_step_t)
  *     a phase still outside [-2pi, 2pi] after ONE wrap (clamp wider than +-2pi, huge amplitudes).
+ * `ign` (a lane mask) takes lanes out of the first test.  It is for symbols that are exactly (+0, +0) -- a stream's first block,
+ * a squelched input, an all-zero frame -- where T is (+-0, +-0) whatever the phase: d = |T.y| - |T.x| = +0, the two updates add
+ * +-0, and x + (+-0) = x for every x but -0, so the stream's step IS the reference's (phase + freq, wrap, clamp; state at rest
+ * stays at rest) as long as neither phase nor freq is -0 -- which only loaded state can be, and the sum of two floats is -0 only if
+ * both are.  The caller checks symbols and state (rx_fused.hip, zero_run) before it sets a lane's bit, per stretch of symbols.
  *
  * Registers: v[100:143] are scratch owned by the block (clobbered; low enough for a kernel built for three
  * waves per SIMD, i.e. at most 168 VGPRs):
@@ -67,6 +72,13 @@ constexpr int COSTAS_ASM_GROUP = 16;
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
     return (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) void *)p;
+}
+
+/* a wave-uniform 64-bit value the compiler cannot see as one (a ballot carried round a divergent loop): into SGPRs */
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+{
+    return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+           (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)v);
 }
 
 #define QPSK_STR_(x) #x
@@ -198,9 +210,10 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 #define QPSK_ZA "%[za]"
 __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, unsigned &d_addr, unsigned &z_addr,
                                                    unsigned groups, float alpha, float beta, float min_freq,
-                                                   float max_freq, unsigned long long &flags_out)
+                                                   float max_freq, unsigned long long &flags_out, unsigned long long ign = 0ull)
 {
     unsigned long long flags, tmp;
+    ign = uniform64(ign);
     const double magic = 0x1.8p52, c3 = -0x1.6c087e89a359dp-10, s2 = 0x1.1107605230bc4p-7;
     double beal;                 /* (beta, alpha) as one VGPR pair for the packed multiply by d */
     {
@@ -234,6 +247,7 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(112), QPSK_RDA(128), 48, "%[p]", "12", "13", "14", "15")
         QPSK_TAIL("%[p]", "%[f]", "116", "216")
         "v_cmp_eq_f32_e64 %[tm], 0, v126\n\t"
+        "s_andn2_b64 %[tm], %[tm], %[ign]\n\t"   /* lanes the caller has looked at: nothing but +0.0 symbols ahead of them (below) */
         "s_or_b64 %[fl], %[fl], %[tm]\n\t"
         "s_cmp_lg_u64 %[fl], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
@@ -270,7 +284,7 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         : [magic] "v"(magic), [c3] "v"(c3), [s2] "v"(s2), [fmax] "v"(max_freq), [beal] "v"(beal),
           [k2pi] "s"(0x1.45F306DC9C883p-1), [hpi] "s"(0x1.921FB54442D18p0), [c4] "s"(0x1.99343027bf8c3p-16),
           [s3] "s"(-0x1.994eb3774cf24p-13), [c2] "s"(0x1.55553e1068f19p-5), [s1] "s"(-0x1.555545995a603p-3),
-          [c1] "s"(-0x1.ffffffd0c621cp-2), [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu)
+          [c1] "s"(-0x1.ffffffd0c621cp-2), [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu), [ign] "s"(ign)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
           "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
           "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135",
@@ -316,9 +330,11 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
 __device__ __forceinline__ void costas_asm_run_ring(float &phase, float &freq, unsigned d_base, unsigned z_base,
                                                     unsigned ready_addr, unsigned consumed_addr, unsigned &k, unsigned kend,
                                                     float alpha, float beta, float min_freq, float max_freq,
-                                                    unsigned long long &flags_out)
+                                                    unsigned long long &flags_out, unsigned long long ign = 0ull)
 {
     unsigned long long flags, tmp, ex;
+    ign = uniform64(ign);
+    kend = __builtin_amdgcn_readfirstlane(kend);
     unsigned t0, t1;
     const double magic = 0x1.8p52, c3 = -0x1.6c087e89a359dp-10, s2 = 0x1.1107605230bc4p-7;
     double beal;
@@ -371,6 +387,7 @@ __device__ __forceinline__ void costas_asm_run_ring(float &phase, float &freq, u
         QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(112), QPSK_RDN, 48, "%[p]", "12", "13", "14", "15")
         QPSK_TAIL("%[p]", "%[f]", "116", "216")
         "v_cmp_eq_f32_e64 %[tm], 0, v126\n\t"
+        "s_andn2_b64 %[tm], %[tm], %[ign]\n\t"   /* lanes the caller has looked at: nothing but +0.0 symbols ahead of them (below) */
         "s_or_b64 %[fl], %[fl], %[tm]\n\t"
         "s_cmp_lg_u64 %[fl], 0\n\t"
         "s_cbranch_scc1 3f\n\t"
@@ -420,7 +437,7 @@ __device__ __forceinline__ void costas_asm_run_ring(float &phase, float &freq, u
           [magic] "v"(magic), [c3] "v"(c3), [s2] "v"(s2), [fmax] "v"(max_freq), [beal] "v"(beal),
           [k2pi] "s"(0x1.45F306DC9C883p-1), [hpi] "s"(0x1.921FB54442D18p0), [c4] "s"(0x1.99343027bf8c3p-16),
           [s3] "s"(-0x1.994eb3774cf24p-13), [c2] "s"(0x1.55553e1068f19p-5), [s1] "s"(-0x1.555545995a603p-3),
-          [c1] "s"(-0x1.ffffffd0c621cp-2), [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu)
+          [c1] "s"(-0x1.ffffffd0c621cp-2), [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu), [ign] "s"(ign)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
           "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
           "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135",

@@ -216,8 +216,12 @@ __device__ __forceinline__ void costas_step_t(float &phase, float &freq, float a
     const bool zero = tx * ty == 0.0f;
     const bool wrap = fabsf(p) >= TAU_F;
     if (__builtin_expect(__any(zero || wrap), 0)) {
-        if (zero) { /* sgn(0) = -1 is not rotation invariant: take the detector on z itself */
-            const float2 z = apply_quadrant(tx, ty, q);
+        if (zero) {
+            /* sgn(0) = -1 is not rotation invariant: take the detector on z itself -- formed as derotate() forms it, from the turned
+             * PAIR (sin, cos): turning T instead gives the same numbers except for the sign of a sum that cancelled to zero (see
+             * there), and that sign reaches the loop when its frequency is a zero too (a loaded -0 frequency in front of zero symbols) */
+            const SinCos sc = sincos_from_raw(w);
+            const float2 z = make_float2(d.x * sc.c + d.y * sc.s, d.y * sc.c - d.x * sc.s);
             e = detector(z.x, z.y);
             f = freq + beta * e;
             p = phase + f + alpha * e;

@@ -215,6 +215,26 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
     const bool fast_clamp = a.min_freq < 0.0f && a.max_freq > 0.0f;
     float ph = st.phase, fr = st.freq;
     bool over = false;   /* a phase beyond the bounded 2 pi wrap (qpsk_device.h, phase_wrap) */
+    /* Symbols that are exactly (+0, +0) -- a stream's first block, a squelched input, an all-zero frame -- trip the instruction
+     * stream's exact-zero test in every group although its step is the reference's for them (costas_asm.h, `ign`).  When a group
+     * is abandoned, the lanes that tripped the test look at the symbols they have ahead in the chunk: nothing but +0.0 there and no
+     * -0 in the loop state excuses them from the test for that stretch, and the stream takes the group again.  Without this such a
+     * lane sent its whole workgroup through the C++ step, six times the cost (a squelched stream among 16; config 2 with one silent
+     * frame: the launch waits for that workgroup). */
+    auto zero_run = [&](int from, int to) {       /* ring slots [from, to) of this lane's row, both even: 16-byte reads */
+        const uint4 *p = reinterpret_cast<const uint4 *>(dl + from);
+        unsigned acc = 0;
+        for (int i = 0; i < (to - from) / 2; i++) {
+            const uint4 v = p[i];
+            acc |= v.x | v.y | v.z | v.w;
+        }
+        return acc == 0u;
+    };
+    auto excusable = [&](unsigned long long lanes, int from, int to) {       /* -> the lanes of `lanes` with such a stretch ahead */
+        const bool z = ((lanes >> lane) & 1ull) != 0ull && __float_as_uint(ph) != 0x80000000u && __float_as_uint(fr) != 0x80000000u &&
+                       zero_run(from, to);
+        return (unsigned long long)__ballot(z);
+    };
     const float al = lg.alpha, be = lg.beta, fmin_ = a.min_freq, fmax_ = a.max_freq;
     bool ok = true;
 #ifdef QPSK_PIPE_PROFILE
@@ -267,27 +287,41 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
                 const unsigned kend = 4u * (unsigned)cfull;
                 const unsigned d_base = lds_addr(dl), z_base = lds_addr(zl);
                 const unsigned ready_addr = lds_addr(&sm->ready[gw]), consumed_addr = lds_addr(&sm->consumed);
+                unsigned long long ign = 0ull;      /* lanes excused from the zero test up to the end of the chunk they are in */
                 while (k < kend) {
                     if ((k & 3u) == 0u) {     /* entering a chunk: the stream left because it was not there yet (or this is the start) */
                         ok = wait_ge(&sm->ready[gw], (int)(k >> 2) + 1, &sm->abort_flag);
                         if (!__all(ok)) { ok = false; break; }
+                        if (ign) {            /* still nothing but zeros?  (the stream stops at every chunk end while some lane is excused) */
+                            const int at = (int)(k & 7u) * AG;
+                            ign = excusable(ign, at, at + S);
+                        }
                     }
-                    unsigned long long fl = 1;
+                    unsigned long long fl = 0ull;
+                    bool ran = false;
                     if (!__any(__float_as_uint(fr) == 0x80000000u)) {
                         unsigned ks = __builtin_amdgcn_readfirstlane(k);
+                        const unsigned kstop = ign ? min(kend, (ks | 3u) + 1u) : kend;
 #ifdef QPSK_PIPE_PROFILE
                         rp_tick(rp_out);
                         if (rp_calls++ == 0) rp_rt1 = rp_real();
 #endif
-                        costas_asm_run_ring(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kend, al, be, fmin_, fmax_, fl);
+                        costas_asm_run_ring(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kstop, al, be, fmin_, fmax_, fl, ign);
+                        ran = true;
 #ifdef QPSK_PIPE_PROFILE
                         rp_tick(rp_in);
                         rp_rt2 = rp_real();
 #endif
                         k = ks;
                     }
-                    if (fl != 0 && k < kend) {      /* group k abandoned (or never started): the C++ step, then on */
+                    if ((!ran || fl != 0ull) && k < kend) {      /* group k abandoned (or never started) */
                         const int at = (int)(k & 7u) * AG;
+                        const unsigned long long fresh = fl & ~ign;
+                        if (ran && fresh) {
+                            const unsigned long long zm = excusable(fresh, at, ((int)(k & 7u) | 3) * AG + AG);
+                            if ((fresh & ~zm) == 0ull) { ign |= zm; continue; }      /* every lane that tripped: the stream again */
+                        }
+                        /* the C++ step, then on */
                         for (int i = 0; i < AG; i++) {
                             float tx, ty; unsigned qq;
                             zl[at + i] = ph;
@@ -340,15 +374,24 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
                  * detector input, double wrap) is redone here with the C++ step, and so is one that would start
                  * with freq = -0 (loaded state only), where the stream's zero error has the wrong sign */
                 constexpr int AG = COSTAS_ASM_GROUP;
+                unsigned long long ign = 0ull;      /* lanes excused from the zero test for the rest of this chunk's whole groups */
                 while (cnt - j >= AG) {
                     unsigned da = lds_addr(dl + slot + j), za = lds_addr(zl + slot + j);
-                    unsigned long long fl;
+                    unsigned long long fl = 0ull;
+                    bool ran = false;
                     const unsigned want = __builtin_amdgcn_readfirstlane((unsigned)(cnt - j) / AG);   /* wave-uniform */
                     unsigned left = want;
-                    if (!__any(__float_as_uint(fr) == 0x80000000u))
-                        left = costas_asm_run(ph, fr, da, za, want, al, be, fmin_, fmax_, fl);
+                    if (!__any(__float_as_uint(fr) == 0x80000000u)) {
+                        left = costas_asm_run(ph, fr, da, za, want, al, be, fmin_, fmax_, fl, ign);
+                        ran = true;
+                    }
                     j += AG * (int)(want - left);
                     if (left != 0) {
+                        const unsigned long long fresh = fl & ~ign;
+                        if (ran && fresh) {
+                            const unsigned long long zm = excusable(fresh, slot + j, slot + j + AG * (int)left);
+                            if ((fresh & ~zm) == 0ull) { ign |= zm; continue; }
+                        }
                         for (int i = 0; i < AG; i++, j++) {
                             float tx, ty; unsigned qq;
                             zl[slot + j] = ph;

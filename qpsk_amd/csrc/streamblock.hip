@@ -123,16 +123,32 @@ __device__ __forceinline__ void stream_block_body(const StreamBlockArgs &a, cons
             }
             if (fast_clamp) {
                 constexpr int AG = COSTAS_ASM_GROUP;
+                unsigned long long ign = 0ull;      /* this lane excused from the stream's exact-zero test (costas_asm.h, `ign`) */
                 while (N - j >= AG) {
                     unsigned da = lds_addr(dsym + j), za = lds_addr(zrec + j);
-                    unsigned long long fl;
+                    unsigned long long fl = 0ull;
+                    bool ran = false;
                     const unsigned want = __builtin_amdgcn_readfirstlane((unsigned)(N - j) / AG);      /* wave-uniform (one lane is active) */
                     unsigned left = want;
-                    if (__float_as_uint(fr) != 0x80000000u)      /* a -0 frequency (loaded state only) stays with the C++ step */
-                        left = costas_asm_run(phs, fr, da, za, want, al, be, fmin_, fmax_, fl);
+                    if (__float_as_uint(fr) != 0x80000000u) {    /* a -0 frequency (loaded state only) stays with the C++ step */
+                        left = costas_asm_run(phs, fr, da, za, want, al, be, fmin_, fmax_, fl, ign);
+                        ran = true;
+                    }
                     j += AG * (int)(want - left);
-                    if (left != 0)      /* the group the stream handed back (exact-zero detector input, double wrap) */
+                    if (left != 0) {    /* the group the stream handed back (exact-zero detector input, double wrap) */
+                        if (ran && (fl & ~ign) != 0ull && __float_as_uint(phs) != 0x80000000u) {
+                            /* nothing but (+0, +0) in the whole groups ahead (a first block, a squelched input): the stream's step is
+                             * the reference's for those -- it takes the group again without the test */
+                            const uint4 *p4 = reinterpret_cast<const uint4 *>(dsym + j);
+                            unsigned acc = 0;
+                            for (int i = 0; i < AG * (int)left / 2; i++) {
+                                const uint4 v = p4[i];
+                                acc |= v.x | v.y | v.z | v.w;
+                            }
+                            if (acc == 0u) { ign = 1ull; continue; }
+                        }
                         for (int i = 0; i < AG; i++, j++) cstep(j);
+                    }
                 }
             }
             for (; j < N; j++) cstep(j);

@@ -1394,3 +1394,44 @@ def test_timing_scan_fused(oracle, L, F):
     for k in ("sym", "costas", "phase", "freq", "index", "hz"):
         assert bits_equal(cpu(a[k]), cpu(b[k])), k
     assert np.array_equal(cpu(a["index"]), cpu(idx))
+
+
+@pytest.mark.parametrize("block", [0, 1])
+def test_streams_stretches_of_zero_symbols(oracle, block):
+    """Symbols that are exactly (+0, +0) -- every stream's first block after qpsk_streams_reset(), a squelched input from its third
+    silent block on -- trip the Costas instruction stream's exact-zero test in every group; the lanes concerned are excused from it
+    for the stretch of zeros they have ahead (costas_asm.h `ign`, rx_fused.hip costas_wave, streamblock.hip) instead of sending the
+    whole workgroup through the C++ step.  Loop states that meet such a stretch: zeros of both signs in phase and frequency (where
+    signed zeros decide: those stay with the C++ step), phases in every quadrant at rest, moving loops that wrap, a frequency at its
+    limit, denormal frequencies; then squelch and signal again.  Every block of every stream against the oracle's modem; block = 1:
+    the one-launch-per-block kernel, 0: the loop kernel of the composition."""
+    fs, rs, L, S = 19200.0, 2400.0, 1024, 40
+    m = modem(fs=fs, rs=rs, frame_size=L)
+    m.tune(stream_block=block)
+    m.streams_reset(S, 1500.0)
+    nz = np.float32(-0.0)
+    states = [(0.0, 0.0), (nz, 0.0), (0.0, nz), (nz, nz), (1.0, 0.0), (2.5, 0.0), (-2.5, nz), (4.0, 0.0), (5.5, nz), (-4.0, 0.0), (-5.5, nz),
+              (-1.0, nz), (0.3, 0.7), (-1.0, -0.9), (6.0, 0.99), (0.0, 1e-30), (3.0, 1.0), (-3.0, -1.0), (6.2831855, 0.0), (-6.2831855, nz),
+              (1.5707964, 0.0), (3.1415927, nz), (0.0, 1e-42), (nz, -1e-42), (2.0, 0.01)]
+    st = np.array([states[i % len(states)] for i in range(S)], np.float32)
+    m._check(m.L.qpsk_streams_set_loop_state(m.h, st.ctypes.data_as(C.POINTER(C.c_float))))
+    om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
+    for s_, o in enumerate(om):
+        o.set_mixer_hz(1500.0)
+        o.s.loop.phase = float(st[s_, 0])
+        o.s.loop.freq = float(st[s_, 1])
+    rng = np.random.default_rng(77)
+    squelched = set(range(0, S, 3))
+    for k in range(7):
+        pcm = (6000 * rng.standard_normal((S, L))).astype(np.int16)
+        if 1 <= k <= 4:
+            for s_ in squelched:
+                pcm[s_] = 0
+        o = m.streams_rx_pcm(pcm)
+        m.sync()
+        for s_ in range(S):
+            om[s_].rx_pcm(pcm[s_])
+            assert cpu(o["index"])[s_] == om[s_].index, (k, s_)
+            assert bits_equal(cpu(o["sym"][s_]), om[s_].symbols), (k, s_)
+            assert bits_equal(cpu(o["costas"][s_]), om[s_].costas_frame), (k, s_)
+            assert cpu(o["phase"])[s_].tobytes() == om[s_].phase.tobytes() and cpu(o["freq"])[s_].tobytes() == om[s_].freq.tobytes(), (k, s_, st[s_])
