@@ -110,7 +110,8 @@ int qpsk_ctx_set_stream(qpsk_ctx *ctx, void *stream);
  * compiler-scheduled full-rate filter and LDS-tap streams also for symmetric taps), "QPSK_FFT_FUSED" (0: the FFT timing estimate always as
  * a launch of its own), "QPSK_STREAM_BLOCK" (0: streams never take the one-launch-per-block kernel, 1: whenever the shape allows),
  * "QPSK_STREAM_POLL" (0: qpsk_streams_rx_pcm_host waits with hipStreamSynchronize), "QPSK_STREAM_SCAN" (streams with histogram
- * timing: 1 = mixer + filter + scan as one kernel whatever the stream count, 0 = never); value < 0 = back to the library's own choice.
+ * timing: 1 = mixer + filter + scan as one kernel whatever the stream count, 0 = never), "QPSK_STREAM_CARRIER" (0: that kernel runs every
+ * stream's carrier recurrence although all streams share one); value < 0 = back to the library's own choice.
  * Environment variables of the same names are read once, by qpsk_ctx_create(), as the context's initial values;
  * no other call reads the environment, and none of them can change a result. */
 int qpsk_ctx_set_tuning(qpsk_ctx *ctx, const char *name, int value);

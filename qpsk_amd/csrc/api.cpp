@@ -70,6 +70,7 @@ struct Tuning {
     int stream_scan = -1;                             /* streams from PCM, histogram timing: 1 = stream_scan_kernel (mixer + filter + scan) whatever the stream count, 0 = never */
     int stream_poll = -1;                             /* qpsk_streams_rx_pcm_host on the one-launch kernel: 0 = wait with hipStreamSynchronize instead of watching the kernel's counter */
     int stream_block = -1;                            /* streams: 0 = never the one-launch-per-block kernel (streamblock.hip), 1 = whenever the shape allows, unset: up to 1024 streams */
+    int stream_carrier = -1;                          /* stream_scan_kernel on PCM: 0 = every stream runs its own carrier (mixer wave) even while all streams share one */
     int fft_fused = -1;                               /* FFT timing estimate: 0 = always a launch of its own (1 / unset: inside rx_fused_pipe_kernel's launch for full workgroups) */
 };
 
@@ -81,7 +82,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
     {"QPSK_PIPE_LAYOUT_LO", &Tuning::layout_lo}, {"QPSK_PIPE_LAYOUT_HI", &Tuning::layout_hi},
     {"QPSK_FIR_GENERIC", &Tuning::fir_generic}, {"QPSK_FFT_FUSED", &Tuning::fft_fused},
     {"QPSK_STREAM_BLOCK", &Tuning::stream_block}, {"QPSK_STREAM_POLL", &Tuning::stream_poll},
-    {"QPSK_STREAM_SCAN", &Tuning::stream_scan},
+    {"QPSK_STREAM_SCAN", &Tuning::stream_scan}, {"QPSK_STREAM_CARRIER", &Tuning::stream_carrier},
 };
 
 /* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
@@ -124,6 +125,14 @@ struct qpsk_ctx {
     /* streams */
     int nstreams = 0;
     float *s_memory = nullptr, *s_dec = nullptr, *s_loop = nullptr, *s_mixer = nullptr;
+    /* the streams' carrier while it is ONE carrier (streamscan.hip MODE 2): qpsk_streams_reset() gives every stream the same mixer
+     * frequency and starting phase, and the carrier does not depend on the data, so it stays one as long as every PCM block goes
+     * through stream_scan_kernel.  s_ctab: two tables of frame_size phases (this block's, the next block's), s_cstate: kernels.h.
+     * Any other consumer of s_mixer first gets the per-stream state back (carrier_to_streams) and the sharing ends until the next reset */
+    float *s_ctab = nullptr, *s_cstate = nullptr;
+    bool carrier_shared = false;
+    unsigned carrier_blocks = 0;
+    float *carrier_pending = nullptr;   /* the table stream_scan_kernel has begun: the loop kernel of the same call finishes it (carrier.h) */
     /* host-pointer streaming call (qpsk_streams_rx_pcm_host: what the drop-in rx_frame() uses): pinned staging on the
      * host, matching arena on the device; sized for nstreams blocks */
     unsigned char *h_stage = nullptr, *d_stage = nullptr;
@@ -305,8 +314,9 @@ static void free_streams(qpsk_ctx *c)
     hipFree(c->d_stage);
     c->h_stage = c->d_stage = nullptr;
     c->stage_cap = 0;
-    hipFree(c->s_memory); hipFree(c->s_dec); hipFree(c->s_loop); hipFree(c->s_mixer);
-    c->s_memory = c->s_dec = c->s_loop = c->s_mixer = nullptr;
+    hipFree(c->s_memory); hipFree(c->s_dec); hipFree(c->s_loop); hipFree(c->s_mixer); hipFree(c->s_ctab); hipFree(c->s_cstate);
+    c->s_memory = c->s_dec = c->s_loop = c->s_mixer = c->s_ctab = c->s_cstate = nullptr;
+    c->carrier_shared = false;
     c->nstreams = 0;
 }
 
@@ -763,7 +773,10 @@ static int costas_over_symbols(qpsk_ctx *c, float *d_symbols, int nframes, int n
                                uint8_t *d_sym, float *d_costas, const float *refill = nullptr,
                                const int32_t *refill_index = nullptr, bool refill_planar = false)
 {
+    float *carrier_tab = c->carrier_pending;
+    c->carrier_pending = nullptr;
     if (tuned(c->tune.generic, 0)) {
+        if (carrier_tab) KERNEL_TRY(launch_carrier_table(c->s_cstate, carrier_tab, c->prm.frame_size, true, c->stream));
         KERNEL_TRY(launch_costas(d_symbols, nframes, nsym, dstride, 1, c->d_gains, c->min_freq, c->max_freq, d_state, d_state,
                                  d_sym, d_costas, c->d_status, c->stream));
         if (refill) {
@@ -793,6 +806,11 @@ static int costas_over_symbols(qpsk_ctx *c, float *d_symbols, int nframes, int n
     a.dsrc = reinterpret_cast<const float2 *>(d_symbols);
     a.dstride = dstride;
     a.status = c->d_status;
+    if (carrier_tab) {
+        a.carrier_state = c->s_cstate;
+        a.carrier_tab = reinterpret_cast<float2 *>(carrier_tab);
+        a.carrier_frame = c->prm.frame_size;
+    }
     a.dbg = tuned(c->tune.pipe_variant, 0) & PIPE_VARIANT_MASK;
     int nf = (nframes + c->ncu * pipe_frames(1) - 1) / (c->ncu * pipe_frames(1));
     if (nf < 1) nf = 1;
@@ -922,6 +940,8 @@ int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, i
 }
 
 /* --------------------------------------------------------------- streams */
+static bool stream_scan_ok(const qpsk_ctx *c, bool pcm);
+
 int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
 {
     if (!c || nstreams <= 0) return fail(QPSK_ERR_ARG, "qpsk_streams_reset: bad argument");
@@ -933,6 +953,8 @@ int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
         if (hipMalloc((void **)&c->s_memory, sizeof(float) * 2 * QPSK_NTAPS * n) != hipSuccess ||
             hipMalloc((void **)&c->s_dec, sizeof(float) * 2 * c->nsym * n) != hipSuccess ||
             hipMalloc((void **)&c->s_loop, sizeof(float) * 2 * n) != hipSuccess ||
+            hipMalloc((void **)&c->s_ctab, sizeof(float) * 2 * 2 * (size_t)c->prm.frame_size) != hipSuccess ||
+            hipMalloc((void **)&c->s_cstate, sizeof(float) * 8) != hipSuccess ||
             hipMalloc((void **)&c->s_mixer, sizeof(float) * 4 * n) != hipSuccess) {
             free_streams(c);
             return fail(QPSK_ERR_ALLOC, "hipMalloc of stream state failed");
@@ -949,7 +971,25 @@ int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
     std::vector<float> m(4 * n);
     for (size_t i = 0; i < n; i++) { m[4 * i] = 1.0f; m[4 * i + 1] = 0.0f; m[4 * i + 2] = rect[0]; m[4 * i + 3] = rect[1]; }
     HIP_TRY(hipMemcpyAsync(c->s_mixer, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice, c->stream));
+    /* one carrier for all of them: the first block's phases now, every later block's by the block before it (streamscan.hip MODE 2) */
+    const float cst[8] = {1.0f, 0.0f, rect[0], rect[1], 1.0f, 0.0f, 0.0f, 0.0f};
+    HIP_TRY(hipMemcpyAsync(c->s_cstate, cst, sizeof cst, hipMemcpyHostToDevice, c->stream));
+    c->carrier_shared = false;
+    c->carrier_blocks = 0;
+    if (stream_scan_ok(c, true)) {      /* (the kernel that uses it would take these streams: whole 256-sample tiles, thousands of them) */
+        KERNEL_TRY(launch_carrier_table(c->s_cstate, c->s_ctab, c->prm.frame_size, false, c->stream));
+        c->carrier_shared = true;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return QPSK_OK;
+}
+
+/* the shared carrier ends: every stream's mixer state = the phase the next block starts from (before any other reader of s_mixer) */
+static int carrier_to_streams(qpsk_ctx *c)
+{
+    if (!c->carrier_shared) return QPSK_OK;
+    KERNEL_TRY(launch_carrier_broadcast(c->s_cstate, c->s_mixer, c->nstreams, c->stream));
+    c->carrier_shared = false;
     return QPSK_OK;
 }
 
@@ -990,6 +1030,8 @@ static int streams_block_launch(qpsk_ctx *c, const int16_t *pcm, const float *cp
                                 uint8_t *sym, float *costas, int32_t *index, const StreamBlockInline *inl = nullptr, bool count = false)
 {
     if (int rg = use_context_gains(c)) return rg;
+    if (pcm)
+        if (int rb = carrier_to_streams(c)) return rb;
     StreamBlockArgs a{};
     a.pcm = pcm;
     a.cplx = reinterpret_cast<const float2 *>(cplx);
@@ -1086,9 +1128,27 @@ static int streams_scanned(qpsk_ctx *c, const int16_t *d_pcm, const float *d_cpl
     if (rf) return rf;
     rf = ensure(c, c->index, sizeof(int32_t) * (size_t)n);
     if (rf) return rf;
+    const float *ctab = nullptr;
+    float *ctab_next = nullptr;
+    if (d_pcm) {
+        if (c->carrier_shared && tuned(c->tune.stream_carrier, 1) != 0) {
+            ctab = c->s_ctab + 2 * (size_t)L * (c->carrier_blocks & 1u);
+            ctab_next = c->s_ctab + 2 * (size_t)L * ((c->carrier_blocks + 1u) & 1u);
+            c->carrier_blocks++;
+            c->carrier_pending = ctab_next;
+        } else if (int rb = carrier_to_streams(c)) {
+            return rb;
+        }
+    }
     KERNEL_TRY(launch_stream_scan(d_pcm, d_cplx, c->s_mixer, c->s_memory, (float *)c->filtered.p, c->d_taps, (int32_t *)c->index.p, n, L,
-                                  c->d_status, c->stream));
-    return streams_from_filter(c, nullptr, true, d_sym, d_freq, d_phase, d_costas, d_index, true);
+                                  c->d_status, c->stream, ctab, ctab_next, c->s_cstate, ctab ? (int)(c->carrier_blocks - 1u) : 0));
+    const int rc = streams_from_filter(c, nullptr, true, d_sym, d_freq, d_phase, d_costas, d_index, true);
+    if (c->carrier_pending) {      /* the loop kernel was never reached: the table is finished all the same */
+        float *tab = c->carrier_pending;
+        c->carrier_pending = nullptr;
+        KERNEL_TRY(launch_carrier_table(c->s_cstate, tab, L, true, c->stream));
+    }
+    return rc;
 }
 
 int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *d_freq, float *d_phase,
@@ -1122,6 +1182,7 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
     int rc = ensure(c, c->mixed, sizeof(float) * 2 * (size_t)n * L);
     if (rc) return rc;
     /* qpsk.c:114-120 */
+    if (int rb = carrier_to_streams(c)) return rb;
     KERNEL_TRY(launch_mixer(d_pcm, (float *)c->mixed.p, c->s_mixer, n, L, c->stream));
     return qpsk_streams_rx_cplx(c, (const float *)c->mixed.p, d_sym, d_freq, d_phase, d_costas, d_index);
 }

@@ -60,6 +60,11 @@ struct FusedArgs {
     float *hz;              /* [nframes][nbw] or NULL */
     int *status;            /* the context's status word (pinned host memory): a kernel stores STATUS_* there when a
                                call's results are invalid (pipeline timeout, phase beyond the bounded 2 pi wrap) */
+    /* costas_pipe_kernel behind stream_scan_kernel MODE 2 (carrier.h): a spare wave of workgroup 0 finishes the carrier table of the
+     * next block.  carrier_state NULL = no spare wave */
+    float *carrier_state;
+    float2 *carrier_tab;
+    int carrier_frame;      /* samples per block of that table */
 };
 
 size_t fused_lds_bytes(int G, int S, int cycles, int nbw);
@@ -164,7 +169,14 @@ int launch_stream_block(const StreamBlockArgs &a, int nstreams, hipStream_t s, c
 int stream_scan_tile(void);
 int prepare_stream_scan(void);
 int launch_stream_scan(const int16_t *pcm, const float *x, float *mixer, float *memory, float *yout, const float *taps, int32_t *index,
-                       int nstreams, int frame_size, int *status, hipStream_t s);   /* exactly one of pcm / x (complex blocks: no mixer) */
+                       int nstreams, int frame_size, int *status, hipStream_t s, const float *ctab = nullptr, float *ctab_next = nullptr,
+                       float *cstate = nullptr, int cseq = 0);
+/* the shared carrier of MODE 2 (streamscan.hip): cstate [8] = {phase the next table starts from, fbb_rx_rect, phase the last table
+ * started from, the relay counter of stream_scan_kernel's spare waves (an int: zero it with cseq = 0), unused}; a table = the frame_size
+ * phases of one block; cseq = the number of MODE 2 launches since that counter was zeroed.  ctab != NULL selects MODE 2: this block's phases from ctab,
+ * the next block's into ctab_next (by a spare wave of workgroup 0), cstate advanced; the per-stream mixer[] is then not touched */
+int launch_carrier_table(float *cstate, float *tab, int frame_size, bool rest_only, hipStream_t s);   /* whole table, or what stream_scan_kernel left (carrier.h) */
+int launch_carrier_broadcast(const float *cstate, float *mixer, int nstreams, hipStream_t s);   /* exactly one of pcm / x (complex blocks: no mixer) */
 /* bitstages.hip */
 int launch_crc16(const uint8_t *data, int npackets, int nbytes, uint16_t *crc, hipStream_t s);
 int launch_interleave(uint8_t *data, int npackets, int nbytes, unsigned b, int dir, hipStream_t s);

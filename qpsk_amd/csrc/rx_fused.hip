@@ -49,6 +49,7 @@
 #include "fir_lean_asm.h"      /* WS_LEAN_SLOTS, the streams */
 #include "fir_full8_asm.h"     /* the in-launch FFT timing estimate of rx_fused_pipe_kernel */
 #include "timing_fft_wave.h"
+#include "carrier.h"
 #ifdef QPSK_PIPE_PROFILE
 #include "fir_lean_prof_asm.h"
 #endif
@@ -521,7 +522,7 @@ __device__ __forceinline__ void flush_records(const FusedArgs &a, const float *z
  * memory into the symbol ring, and the flush of consumed records.
  * a.dsrc rows are a.dstride symbols apart; one loop per frame (nbw = 1).
  * ======================================================================== */
-__global__ void __launch_bounds__(64 * (GeomNarrow::MAX_NF + 1))
+__global__ void __launch_bounds__(64 * (GeomNarrow::MAX_NF + 2))
 costas_pipe_kernel(FusedArgs a, int *status)
 {
     using GM = GeomNarrow;
@@ -529,7 +530,7 @@ costas_pipe_kernel(FusedArgs a, int *status)
     static_assert(R == 2 || R == 4, "flush_records packs 2 or 4 symbols per store");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem *sm = reinterpret_cast<Smem *>(smem_raw);
-    const int NF = (int)blockDim.x / 64 - 1;
+    const int NF = (int)blockDim.x / 64 - 1 - (a.carrier_state ? 1 : 0);
     const int G = NF * FWV;
     float2 *dring = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));     /* [G][DSTRIDE] */
     float *zring = reinterpret_cast<float *>(dring + (size_t)G * DSTRIDE);  /* [G][ZSTRIDE] */
@@ -543,6 +544,11 @@ costas_pipe_kernel(FusedArgs a, int *status)
 
     if (wave == 0) {
         costas_wave<GM>(a, sm, dring, zring, G, f0, lane, nchunks, status);
+        return;
+    }
+    if (wave == NF + 1) {      /* the spare wave (streams behind stream_scan_kernel MODE 2): the rest of the next block's carrier table */
+        if (blockIdx.x == 0 && lane == 0)
+            carrier_block(a.carrier_state, a.carrier_tab, a.carrier_frame, carrier_split(a.carrier_frame), a.carrier_frame / 2);
         return;
     }
     const int w = wave - 1;
@@ -1728,7 +1734,7 @@ int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
     const int G = NF * GM::FWV;
     const int blocks = (a.nframes + G - 1) / G;
     const size_t lds = sizeof(Smem) + sizeof(float2) * (size_t)G * GM::DSTRIDE + sizeof(float) * (size_t)G * GM::ZSTRIDE;
-    hipLaunchKernelGGL(costas_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1)), lds, s, a, status);
+    hipLaunchKernelGGL(costas_pipe_kernel, dim3(blocks), dim3(64 * (NF + 1 + (a.carrier_state ? 1 : 0))), lds, s, a, status);
     return (int)hipGetLastError();
 }
 

@@ -29,6 +29,7 @@
 #include "qpsk_device.h"
 #include "costas_asm.h"      /* lds_addr() */
 #include "fir_full8s_asm.h"
+#include "carrier.h"
 #include "kernels.h"
 
 namespace qpsk {
@@ -45,6 +46,7 @@ constexpr int PITCH = TILE + 4;       /* floats per plane row of the scan ring *
 constexpr int PROW = TILE + 2;        /* float2 slots per phase row: 16 bytes of padding (the mixer's lanes store to different banks) */
 constexpr int THREADS = 64 * (NSCAN + NFIR + 1);
 constexpr int SPIN_LIMIT = 1 << 24;
+constexpr int CARRIER_RELAY = 8;      /* MODE 2: workgroups whose spare waves share stream_scan_kernel's stretch of the next carrier table */
 __device__ __host__ constexpr int slot_of(int p) { return p + PADS * (p / R); }
 static_assert(slot_of(TILE + HIST - 1) < WSF && FIR_FULL8S_ASM_END_VGPR <= 128, "window geometry; 13 waves = four per SIMD");
 
@@ -81,14 +83,39 @@ __device__ __forceinline__ void publish(int *p, int v)
 }
 } // namespace sscan
 
-/* PCM = false: the streams' blocks are already complex (qpsk_streams_rx_cplx: they enter at the rrc_fir() call) -- no mixer wave, the
- * filter waves load 16-byte pairs a tile ahead */
-template <bool PCM>
-__global__ void __launch_bounds__(PCM ? sscan::THREADS : sscan::THREADS - 64)
+/* the first block's table (qpsk_streams_reset); the second part of a table when no loop kernel with a spare wave follows */
+__global__ void __launch_bounds__(64) carrier_table_kernel(float *st, float2 *tab, int frame_size, int from, int to)
+{
+    if (threadIdx.x == 0) carrier_block(st, tab, frame_size, from, to);
+}
+
+/* leaving the shared carrier: every stream's own mixer state = the phase the next block starts from */
+__global__ void __launch_bounds__(256) carrier_broadcast_kernel(const float *st, float *mixer, int nstreams)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < nstreams) {
+        mixer[4 * f] = st[4];
+        mixer[4 * f + 1] = st[5];
+    }
+}
+
+/* MODE 0: the streams' blocks are already complex (qpsk_streams_rx_cplx: they enter at the rrc_fir() call) -- no mixer wave, the
+ * filter waves load 16-byte pairs a tile ahead.
+ * MODE 1: PCM, every stream with its own carrier state (the mixer wave described above).
+ * MODE 2: PCM, ONE carrier for all streams -- what qpsk_streams_reset() sets up (one mixer frequency, one starting phase) and what
+ * stays true as long as every block of the streams comes through here: the carrier does not depend on the data.  Its 16384 dependent
+ * steps per block are then run ONCE (carrier.h: the first 11/16 by a spare wave of workgroup 0 here, the rest by a spare wave of the
+ * loop kernel that follows), for the NEXT block (ctab_next), while every workgroup's filter waves take this block's phases from the
+ * table the call before left (ctab, 128 KB, read through the caches): no mixer wave paces the filter waves (256 steps per tile at
+ * ~110 cycles beside three busy waves was what MODE 1 waits for) and no phase ring. */
+template <int MODE>
+__global__ void __launch_bounds__(MODE ? sscan::THREADS : sscan::THREADS - 64)
 stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x, float *mixer, float2 *memory, float2 *__restrict__ yout,
-                   const float *__restrict__ taps_g, int32_t *index, int nstreams, int frame_size, int *status)
+                   const float *__restrict__ taps_g, int32_t *index, int nstreams, int frame_size, int *status,
+                   const float2 *__restrict__ ctab, float2 *ctab_next, float *cstate, int cseq)
 {
     using namespace sscan;
+    constexpr bool PCM = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Smem *sm = reinterpret_cast<Smem *>(smem_raw);
     float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Smem));                 /* [G][WSF] */
@@ -104,7 +131,37 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
     if (tid == 0) { sm->abort_flag = 0; sm->mready = 0; }
     __syncthreads();
 
-    if (PCM && wave == NSCAN + NFIR) {
+    if (MODE == 2 && wave == NSCAN + NFIR) {
+        /* ============================ the spare wave: workgroup 0's runs the carrier of the NEXT block ====================== */
+        /* The chain costs the SIMD it runs on 12 issue cycles per step, which its workgroup's filter waves miss: spread over the
+         * spare waves of the first CARRIER_RELAY workgroups, one stretch each, in turn (a counter in memory: stretch j of block
+         * number cseq starts when the counter reads cseq * parts + j; workgroups are dispatched in order, so the one waited for is
+         * resident or done).  A relay wave that is not yet on sleeps; the stretch before it takes ~0.06 ms. */
+        const int parts = min(CARRIER_RELAY, (int)gridDim.x);
+        if ((int)blockIdx.x < parts && lane == 0) {
+            const int split = carrier_split(frame_size), per = ((split + parts - 1) / parts + 3) & ~3;
+            const int from = min((int)blockIdx.x * per, split), to = min(from + per, split);
+            int *ctr = reinterpret_cast<int *>(cstate + 6);
+            const int turn = cseq * parts + (int)blockIdx.x;
+            int spins = 0;
+            bool ok = true;
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != turn) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > SPIN_LIMIT) { ok = false; break; }
+            }
+            if (ok) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __builtin_amdgcn_s_setprio(3);
+                carrier_block(cstate, ctab_next, frame_size, from, to);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_store(ctr, turn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(status, STATUS_PIPE_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    if (MODE == 1 && wave == NSCAN + NFIR) {
         /* ===================================== the mixer wave: lane s = stream f0 + s ================================= */
         __builtin_amdgcn_s_setprio(3);      /* a latency chain: few issue slots, wanted at once */
         const bool mine = lane < G && f0 + lane < nstreams;
@@ -158,7 +215,9 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
 
     if (wave < NSCAN) {
         /* ================================ scan wave: streams 4*wave .. 4*wave+3 of the workgroup (timing_scan_kernel's) ====== */
-        __builtin_amdgcn_s_setprio(3);
+        /* (workgroup 0's first scan wave shares its SIMD with the carrier wave of MODE 2, the longer chain of the two: it steps back) */
+        if (MODE == 2 && blockIdx.x == 0 && wave == 0) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
         const int fl = lane >> 4, comp = (lane >> 3) & 1, q = lane & 7;      /* lane = 16*stream + 8*component + q */
         const int g = 4 * wave + fl;
         const float qf = (float)q;
@@ -218,7 +277,9 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
     const unsigned rd_addr = lds_addr(mywin + fl * WSF + (R + PADS) * q);   /* position 8q -> slot 10q */
     const int p0 = 2 * lane + HIST;      /* window position of sample 2 lane of a tile */
     float4 hist[UF], pre[UF][2], nxt[UF][2];
+    float4 pc[2];                 /* MODE 2: the phases of the lane's two sample pairs, a tile ahead like the PCM */
     uint32_t pv[UF][2];
+    const float4 *ctab4 = reinterpret_cast<const float4 *>(ctab);
 #pragma unroll
     for (int ff = 0; ff < UF; ff++) {
         /* the delay line (memory[0] is shifted out by the first step, rrc_fir.c:19): the lane's pair of the "block" in front of the
@@ -230,6 +291,10 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
         }
     }
     auto prefetch = [&](int t) {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) pc[j] = ctab4[(t * TILE + 128 * j) / 2 + lane];
+        }
 #pragma unroll
         for (int ff = 0; ff < UF; ff++)
 #pragma unroll
@@ -247,7 +312,17 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
             else if (pt < t) __builtin_amdgcn_s_setprio(0);
             else __builtin_amdgcn_s_setprio(1);
         }
-        if constexpr (PCM) {
+        if constexpr (MODE == 2) {
+            /* qpsk.c:117 with the shared carrier's phases */
+#pragma unroll
+            for (int ff = 0; ff < UF; ff++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const float4 c = pc[j];
+                    const float v0 = (float)(int16_t)(pv[ff][j] & 0xffffu) / 16384.0f, v1 = (float)(int16_t)(pv[ff][j] >> 16) / 16384.0f;
+                    pre[ff][j] = fv[ff] ? make_float4(c.x * v0, c.y * v0, c.z * v1, c.w * v1) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+        } else if constexpr (MODE == 1) {
             /* this tile's carrier phases, then qpsk.c:117: input_frame[i] = fbb_rx_phase * ((float) in[i] / 16384.0f) */
             ok = wait_ge(&sm->mready, t + 1, &sm->abort_flag);
             if (!ok) break;
@@ -314,27 +389,50 @@ int stream_scan_tile(void) { return sscan::TILE; }
 
 int prepare_stream_scan(void)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stream_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(stream_scan_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(stream_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(stream_scan_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(stream_scan_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+}
+
+/* the shared carrier (MODE 2): cstate as kernels.h describes it */
+int launch_carrier_table(float *cstate, float *tab, int frame_size, bool rest_only, hipStream_t s)
+{
+    hipLaunchKernelGGL(carrier_table_kernel, dim3(1), dim3(64), 0, s, cstate, reinterpret_cast<float2 *>(tab), frame_size,
+                       rest_only ? carrier_split(frame_size) : 0, frame_size / 2);
+    return (int)hipGetLastError();
+}
+
+int launch_carrier_broadcast(const float *cstate, float *mixer, int nstreams, hipStream_t s)
+{
+    hipLaunchKernelGGL(carrier_broadcast_kernel, dim3((nstreams + 255) / 256), dim3(256), 0, s, cstate, mixer, nstreams);
+    return (int)hipGetLastError();
 }
 
 /* CYCLES = 8, frame_size % 256 == 0, symmetric taps, 16-byte aligned yout (the caller checks); exactly one of pcm (4-byte aligned rows;
  * mixer state updated) and x (16-byte aligned complex blocks); yout [nstreams][8][frame_size / 8] */
 int launch_stream_scan(const int16_t *pcm, const float *x, float *mixer, float *memory, float *yout, const float *taps, int32_t *index,
-                       int nstreams, int frame_size, int *status, hipStream_t s)
+                       int nstreams, int frame_size, int *status, hipStream_t s, const float *ctab, float *ctab_next, float *cstate, int cseq)
 {
     using namespace sscan;
     if (frame_size % TILE != 0 || (pcm != nullptr) == (x != nullptr) || (reinterpret_cast<uintptr_t>(pcm) & 3) != 0 ||
-        (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(yout) & 15) != 0)
+        (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(yout) & 15) != 0 ||
+        (reinterpret_cast<uintptr_t>(ctab) & 15) != 0 || (reinterpret_cast<uintptr_t>(ctab_next) & 15) != 0 ||
+        (ctab != nullptr && (!pcm || !ctab_next || !cstate)))
         return (int)hipErrorInvalidValue;
     const dim3 grid((nstreams + G - 1) / G);
-    if (pcm)
-        hipLaunchKernelGGL(stream_scan_kernel<true>, grid, dim3(THREADS), LDS_BYTES, s, pcm, nullptr, mixer, reinterpret_cast<float2 *>(memory),
-                           reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status);
+    if (pcm && ctab)
+        hipLaunchKernelGGL(stream_scan_kernel<2>, grid, dim3(THREADS), LDS_BYTES, s, pcm, nullptr, mixer, reinterpret_cast<float2 *>(memory),
+                           reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status,
+                           reinterpret_cast<const float2 *>(ctab), reinterpret_cast<float2 *>(ctab_next), cstate, cseq);
+    else if (pcm)
+        hipLaunchKernelGGL(stream_scan_kernel<1>, grid, dim3(THREADS), LDS_BYTES, s, pcm, nullptr, mixer, reinterpret_cast<float2 *>(memory),
+                           reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status, nullptr, nullptr, nullptr, 0);
     else
-        hipLaunchKernelGGL(stream_scan_kernel<false>, grid, dim3(THREADS - 64), LDS_BYTES, s, nullptr, reinterpret_cast<const float2 *>(x), mixer,
-                           reinterpret_cast<float2 *>(memory), reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status);
+        hipLaunchKernelGGL(stream_scan_kernel<0>, grid, dim3(THREADS - 64), LDS_BYTES, s, nullptr, reinterpret_cast<const float2 *>(x), mixer,
+                           reinterpret_cast<float2 *>(memory), reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status,
+                           nullptr, nullptr, nullptr, 0);
     return (int)hipGetLastError();
 }
 

@@ -1025,18 +1025,21 @@ def test_stream_block_kernel_shapes(oracle, fs, L, S, fixed):
             assert cpu(o["phase"])[s_] == om[s_].phase and cpu(o["freq"])[s_] == om[s_].freq, (k, s_)
 
 
+@pytest.mark.parametrize("carrier", [1, 0])
 @pytest.mark.parametrize("L,S", [(2048, 47), (256, 33), (1024, 16), (4096, 5)])
-def test_streams_pcm_mixer_filter_and_scan_in_one_kernel(oracle, L, S):
-    """stream_scan_kernel (PCM in; the carrier recurrences of a workgroup's 16 streams a tile ahead of its filter waves, the scan fed
-    from LDS, the filtered block left planar by decimation phase for the loop kernel's picks) block after block against the oracle's
-    modems: several workgroups and a ragged last one, one to sixteen tiles per block, state carried through five blocks (delay
-    lines, carrier phase, loop, picks), an all-zero block; and equal to the four kernels apart bit for bit"""
+def test_streams_pcm_mixer_filter_and_scan_in_one_kernel(oracle, L, S, carrier):
+    """stream_scan_kernel (PCM in; the scan fed from LDS, the filtered block left planar by decimation phase for the loop kernel's
+    picks) block after block against the oracle's modems: several workgroups and a ragged last one, one to sixteen tiles per block,
+    state carried through five blocks (delay lines, carrier phase, loop, picks), an all-zero block; and equal to the four kernels
+    apart bit for bit.  carrier = 1: the streams' ONE carrier from the table the block before left (a spare wave of workgroup 0 runs
+    the next block's); 0: the carrier recurrences of a workgroup's 16 streams by its mixer wave, a tile ahead of its filter waves"""
     fs, rs = 19200.0, 2400.0
     m = modem(fs=fs, rs=rs, frame_size=L)
     m2 = modem(fs=fs, rs=rs, frame_size=L)
     for mm, scan in ((m, 1), (m2, 0)):
         mm.tune(stream_block=0)
         mm.tune(stream_scan=scan)
+        mm.tune(stream_carrier=carrier)
         mm.streams_reset(S, 1500.0)
     om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
     for o in om:
@@ -1435,3 +1438,35 @@ def test_streams_stretches_of_zero_symbols(oracle, block):
             assert bits_equal(cpu(o["sym"][s_]), om[s_].symbols), (k, s_)
             assert bits_equal(cpu(o["costas"][s_]), om[s_].costas_frame), (k, s_)
             assert cpu(o["phase"])[s_].tobytes() == om[s_].phase.tobytes() and cpu(o["freq"])[s_].tobytes() == om[s_].freq.tobytes(), (k, s_, st[s_])
+
+
+def test_streams_leave_the_shared_carrier(oracle):
+    """the streams' one carrier (stream_scan_kernel's table, advanced a block ahead by a spare wave) handed back to the per-stream mixer
+    state when another kernel takes over: two blocks through the table, two through the kernels apart (mixer_kernel reads every
+    stream's own state), one through the one-launch-per-block kernel, two through stream_scan_kernel again (now with its mixer wave),
+    a reset, and the table again; every block against the oracle's modems"""
+    fs, rs, L, S = 19200.0, 2400.0, 512, 21
+    m = modem(fs=fs, rs=rs, frame_size=L)
+    m.tune(stream_block=0)
+    m.tune(stream_scan=1)
+    rng = np.random.default_rng(99)
+    for round_ in range(2):
+        m.tune(stream_block=0)
+        m.tune(stream_scan=1)
+        m.streams_reset(S, 1350.0)
+        om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
+        for o in om:
+            o.set_mixer_hz(1350.0)
+        for k, (scan, block) in enumerate([(1, 0), (1, 0), (0, 0), (0, 0), (0, 1), (1, 0), (1, 0)]):
+            m.tune(stream_scan=scan)
+            m.tune(stream_block=block)
+            pcm = (7000 * rng.standard_normal((S, L))).astype(np.int16)
+            o = m.streams_rx_pcm(pcm)
+            m.sync()
+            want_kernel = "stream_block_kernel" if block else ("stream_scan_kernel + costas_pipe_kernel" if scan else "filter, timing, costas_pipe_kernel")
+            assert m.last_kernel() == want_kernel
+            for s_ in range(S):
+                om[s_].rx_pcm(pcm[s_])
+                assert cpu(o["index"])[s_] == om[s_].index, (round_, k, s_)
+                assert bits_equal(cpu(o["sym"][s_]), om[s_].symbols) and bits_equal(cpu(o["costas"][s_]), om[s_].costas_frame), (round_, k, s_)
+                assert cpu(o["phase"])[s_] == om[s_].phase and cpu(o["freq"])[s_] == om[s_].freq, (round_, k, s_)
