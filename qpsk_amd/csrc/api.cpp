@@ -940,7 +940,7 @@ int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, i
 }
 
 /* --------------------------------------------------------------- streams */
-static bool stream_scan_ok(const qpsk_ctx *c, bool pcm);
+static bool stream_scan_ok(const qpsk_ctx *c, bool pcm, bool shared_carrier);
 
 int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
 {
@@ -976,7 +976,7 @@ int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
     HIP_TRY(hipMemcpyAsync(c->s_cstate, cst, sizeof cst, hipMemcpyHostToDevice, c->stream));
     c->carrier_shared = false;
     c->carrier_blocks = 0;
-    if (stream_scan_ok(c, true)) {      /* (the kernel that uses it would take these streams: whole 256-sample tiles, thousands of them) */
+    if (stream_scan_ok(c, true, true)) {      /* (the kernel that uses it would take these streams: whole 256-sample tiles, thousands of them) */
         KERNEL_TRY(launch_carrier_table(c->s_cstate, c->s_ctab, c->prm.frame_size, false, c->stream));
         c->carrier_shared = true;
     }
@@ -1110,11 +1110,13 @@ static int streams_from_filter(qpsk_ctx *c, const float *d_in, bool filtered, ui
  * of the filter waves of the same workgroup, PCM comes in at 2 bytes per sample, no mixed block goes through HBM and the scan
  * reads the filtered samples from LDS.  A workgroup takes 16 streams through the whole block (its time does not shrink with the
  * batch), so it pays from about 2500 streams on; below that the kernels apart are quicker. */
-static bool stream_scan_ok(const qpsk_ctx *c, bool pcm)
+static bool stream_scan_ok(const qpsk_ctx *c, bool pcm, bool shared_carrier)
 {
     /* [measured, profiles/r04_streams_blocks.txt] 2560 streams: PCM input 0.94 against 1.03 ms per block with the kernels apart, complex
-     * input 0.79 against 0.70; 4096 streams: 1.00 against 1.27 and 0.92 against 1.01 */
-    const int from = pcm ? 2560 : 3584;
+     * input 0.79 against 0.70; 4096 streams: 1.00 against 1.27 and 0.92 against 1.01.  With the streams' one carrier from the table
+     * (MODE 2: no mixer wave, no mixer kernel) PCM input pays from 1024 streams on: 0.73 against 0.79 ms there, 0.75 against 0.93 at
+     * 2048, 0.76 against 1.00 at 2560 (profiles/r04_streams_carrier.txt) */
+    const int from = pcm ? (shared_carrier ? 1024 : 2560) : 3584;
     return c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0 && tuned(c->tune.generic, 0) == 0 && c->cycles == 8 &&
            c->prm.timing_mode == QPSK_TIMING_HIST && c->prm.frame_size % stream_scan_tile() == 0 &&
            tuned(c->tune.stream_scan, c->nstreams >= from ? 1 : 0) != 0;
@@ -1161,7 +1163,7 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
         if (int rb = streams_block_launch(c, nullptr, d_in, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
         return streams_copy_loop(c, d_freq, d_phase);
     }
-    if (stream_scan_ok(c, false) && ((uintptr_t)d_in % 16) == 0)
+    if (stream_scan_ok(c, false, false) && ((uintptr_t)d_in % 16) == 0)
         return streams_scanned(c, nullptr, d_in, d_sym, d_freq, d_phase, d_costas, d_index);
     return streams_from_filter(c, d_in, false, d_sym, d_freq, d_phase, d_costas, d_index);
 }
@@ -1177,7 +1179,7 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
         return streams_copy_loop(c, d_freq, d_phase);
     }
     const int n = c->nstreams, L = c->prm.frame_size;
-    if (stream_scan_ok(c, true) && ((uintptr_t)d_pcm % 4) == 0)
+    if (stream_scan_ok(c, true, c->carrier_shared && tuned(c->tune.stream_carrier, 1) != 0) && ((uintptr_t)d_pcm % 4) == 0)
         return streams_scanned(c, d_pcm, nullptr, d_sym, d_freq, d_phase, d_costas, d_index);
     int rc = ensure(c, c->mixed, sizeof(float) * 2 * (size_t)n * L);
     if (rc) return rc;
