@@ -21,6 +21,8 @@
  *                leaves the tile's 256 phases in the stream's row of a one-tile ring; it starts tile t + 1 once every filter wave
  *                has picked tile t up -- i.e. while they filter it.
  * LDS: windows 61,440 + scan ring 66,560 + phase ring 33,024 + counters: 161 KB of the CU's 160 KiB (163,840 bytes).
+ * While all streams share ONE carrier (the state qpsk_streams_reset() leaves, and the carrier does not depend on the data) wave 12 has
+ * nothing to do per workgroup: the block's phases come from a table the call before prepared (MODE 2 below, carrier.h).
  *
  * Served (host-checked): CYCLES = 8, frame_size a multiple of 256, symmetric taps, 4-byte aligned PCM rows, 16-byte aligned output.
  */
