@@ -131,7 +131,8 @@ struct qpsk_ctx {
      * Any other consumer of s_mixer first gets the per-stream state back (carrier_to_streams) and the sharing ends until the next reset */
     float *s_ctab = nullptr, *s_cstate = nullptr;
     bool carrier_shared = false;
-    unsigned carrier_blocks = 0;
+    unsigned carrier_blocks = 0;        /* blocks taken from the tables since the reset (which of the two holds the current one) */
+    unsigned carrier_scans = 0;         /* stream_scan_kernel launches among them (its relay counter, kernels.h) */
     float *carrier_pending = nullptr;   /* the table stream_scan_kernel has begun: the loop kernel of the same call finishes it (carrier.h) */
     /* host-pointer streaming call (qpsk_streams_rx_pcm_host: what the drop-in rx_frame() uses): pinned staging on the
      * host, matching arena on the device; sized for nstreams blocks */
@@ -941,6 +942,7 @@ int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, i
 
 /* --------------------------------------------------------------- streams */
 static bool stream_scan_ok(const qpsk_ctx *c, bool pcm, bool shared_carrier);
+static bool stream_block_ok(const qpsk_ctx *c);
 
 int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
 {
@@ -976,7 +978,8 @@ int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
     HIP_TRY(hipMemcpyAsync(c->s_cstate, cst, sizeof cst, hipMemcpyHostToDevice, c->stream));
     c->carrier_shared = false;
     c->carrier_blocks = 0;
-    if (stream_scan_ok(c, true, true)) {      /* (the kernel that uses it would take these streams: whole 256-sample tiles, thousands of them) */
+    c->carrier_scans = 0;
+    if (c->prm.frame_size % 2 == 0 && (stream_scan_ok(c, true, true) || stream_block_ok(c))) {      /* (a kernel that uses it would take these streams) */
         KERNEL_TRY(launch_carrier_table(c->s_cstate, c->s_ctab, c->prm.frame_size, false, c->stream));
         c->carrier_shared = true;
     }
@@ -1030,9 +1033,19 @@ static int streams_block_launch(qpsk_ctx *c, const int16_t *pcm, const float *cp
                                 uint8_t *sym, float *costas, int32_t *index, const StreamBlockInline *inl = nullptr, bool count = false)
 {
     if (int rg = use_context_gains(c)) return rg;
-    if (pcm)
-        if (int rb = carrier_to_streams(c)) return rb;
     StreamBlockArgs a{};
+    if (pcm) {
+        if (c->carrier_shared && tuned(c->tune.stream_carrier, 1) != 0 && c->prm.frame_size % 2 == 0) {
+            /* the streams' one carrier (carrier.h): this block's phases from the table, the next block's by workgroup 0's third wave */
+            const size_t L2 = 2 * (size_t)c->prm.frame_size;
+            a.ctab = reinterpret_cast<const float2 *>(c->s_ctab + L2 * (c->carrier_blocks & 1u));
+            a.ctab_next = reinterpret_cast<float2 *>(c->s_ctab + L2 * ((c->carrier_blocks + 1u) & 1u));
+            a.cstate = c->s_cstate;
+            c->carrier_blocks++;
+        } else if (int rb = carrier_to_streams(c)) {
+            return rb;
+        }
+    }
     a.pcm = pcm;
     a.cplx = reinterpret_cast<const float2 *>(cplx);
     a.mixer = c->s_mixer;
@@ -1143,7 +1156,7 @@ static int streams_scanned(qpsk_ctx *c, const int16_t *d_pcm, const float *d_cpl
         }
     }
     KERNEL_TRY(launch_stream_scan(d_pcm, d_cplx, c->s_mixer, c->s_memory, (float *)c->filtered.p, c->d_taps, (int32_t *)c->index.p, n, L,
-                                  c->d_status, c->stream, ctab, ctab_next, c->s_cstate, ctab ? (int)(c->carrier_blocks - 1u) : 0));
+                                  c->d_status, c->stream, ctab, ctab_next, c->s_cstate, ctab ? (int)c->carrier_scans++ : 0));
     const int rc = streams_from_filter(c, nullptr, true, d_sym, d_freq, d_phase, d_costas, d_index, true);
     if (c->carrier_pending) {      /* the loop kernel was never reached: the table is finished all the same */
         float *tab = c->carrier_pending;

@@ -150,6 +150,12 @@ struct StreamBlockArgs {
     int *status;
     unsigned *done;         /* mapped pinned host counter or NULL: every wave adds 1 behind its last store (system scope), so the host
                                can watch the block finish instead of going through the stream's completion signal */
+    /* the streams' ONE carrier (carrier.h; set together or not at all): this block's phases from ctab instead of each stream's own
+     * recurrence (the longest stretch of wave 1's chain), the next block's into ctab_next by a third wave of workgroup 0 beside the
+     * Costas wave; `mixer` is then neither read nor written */
+    const float2 *ctab;
+    float2 *ctab_next;
+    float *cstate;
 };
 /* Blocks small enough travel INSIDE the kernel arguments (the dispatch packet's argument buffer is device memory the host writes
  * through the PCIe aperture: posted writes), so the kernel never reads host memory -- on this pool a read of pinned host memory

@@ -27,6 +27,7 @@
 #include "qpsk_device.h"
 #include "costas_asm.h"
 #include "fir_full8_asm.h"
+#include "carrier.h"
 #include "kernels.h"
 
 namespace qpsk {
@@ -90,6 +91,13 @@ __device__ __forceinline__ void stream_block_body(const StreamBlockArgs &a, cons
     }
     __syncthreads();      /* decimated_frame[] is in LDS: wave 1 may overwrite the global copy from here on */
 
+    if (wave == 2) {      /* the spare wave (launched only with the shared carrier): workgroup 0's runs the carrier of the NEXT block */
+        if (s == 0 && lane == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            carrier_block(a.cstate, a.ctab_next, L, 0, L / 2);
+        }
+        return;
+    }
     SBLK_STAMP(1);
     if (wave == 0) {
         /* ============================ Costas + slicer over the previous block's symbols (qpsk.c:196-212) ========= */
@@ -181,7 +189,15 @@ __device__ __forceinline__ void stream_block_body(const StreamBlockArgs &a, cons
     const float2 *mem = a.memory + (size_t)s * NTAPS;
     for (int i = lane; i < HIST; i += 64) xs[i] = mem[i + 1];
     for (int i = HIST + L + lane; i < xs_slots(L); i += 64) xs[i] = make_float2(0.0f, 0.0f);
-    if (a.pcm) {
+    if (a.pcm && a.ctab) {
+        /* qpsk.c:114-120 with the streams' one carrier: the block's phases are in the table the call before left -- no recurrence here */
+        const int16_t *pcm = (INLINE ? reinterpret_cast<const int16_t *>(inl->pcm) : a.pcm) + (size_t)s * L;
+        for (int i = lane; i < L; i += 64) {
+            const float v = (float)pcm[i] / 16384.0f;
+            const float2 c = a.ctab[i];
+            xs[HIST + i] = make_float2(c.x * v, c.y * v);      /* qpsk.c:117 */
+        }
+    } else if (a.pcm) {
         /* qpsk.c:114-120.  The carrier state is fetched and WAITED FOR before the PCM loads are issued (loads return in order: a
          * wait for a later one would wait for the PCM too, which may cross PCIe); the carrier recurrence then runs in their shadow */
         float2 p = make_float2(a.mixer[4 * s], a.mixer[4 * s + 1]);
@@ -386,14 +402,14 @@ __device__ __forceinline__ void stream_block_body(const StreamBlockArgs &a, cons
 #endif
 }
 
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(192)
 stream_block_kernel(StreamBlockArgs a)
 {
     stream_block_body<false>(a, nullptr);
 }
 
 /* the same with the block inside the kernel arguments (kernels.h, StreamBlockInline) */
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(192)
 stream_block_inline_kernel(StreamBlockArgs a, StreamBlockInline)
 {
     /* read where the dispatch left it (taking the parameter's address would copy its 2 KB to scratch): the second argument
@@ -425,14 +441,16 @@ int prepare_stream_block(void)
 
 int launch_stream_block(const StreamBlockArgs &a, int nstreams, hipStream_t s, const StreamBlockInline *inl)
 {
-    if (a.frame_size < 1 || a.frame_size > sblk::MAX_L || a.nsym < 1 || stream_block_lds_bytes(a.frame_size, a.nsym) > (size_t)MAX_LDS_BYTES)
+    if (a.frame_size < 1 || a.frame_size > sblk::MAX_L || a.nsym < 1 || stream_block_lds_bytes(a.frame_size, a.nsym) > (size_t)MAX_LDS_BYTES ||
+        (a.ctab != nullptr) != (a.ctab_next != nullptr) || (a.ctab != nullptr) != (a.cstate != nullptr) || (a.ctab && (a.frame_size & 1)))
         return (int)hipErrorInvalidValue;
+    const dim3 threads(a.ctab ? 192 : 128);
     if (inl) {
         if (nstreams > StreamBlockInline::MAX_STREAMS || (long long)nstreams * a.frame_size > StreamBlockInline::MAX_SAMPLES) return (int)hipErrorInvalidValue;
-        hipLaunchKernelGGL(stream_block_inline_kernel, dim3(nstreams), dim3(128), stream_block_lds_bytes(a.frame_size, a.nsym), s, a, *inl);
+        hipLaunchKernelGGL(stream_block_inline_kernel, dim3(nstreams), threads, stream_block_lds_bytes(a.frame_size, a.nsym), s, a, *inl);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(stream_block_kernel, dim3(nstreams), dim3(128), stream_block_lds_bytes(a.frame_size, a.nsym), s, a);
+    hipLaunchKernelGGL(stream_block_kernel, dim3(nstreams), threads, stream_block_lds_bytes(a.frame_size, a.nsym), s, a);
     return (int)hipGetLastError();
 }
 

@@ -996,7 +996,8 @@ def test_streams_cplx_vs_oracle(oracle, generic, L, S):
 
 @pytest.mark.parametrize("fs,L,S,fixed", [(12000.0, 1000, 3, None), (19200.0, 520, 2, None), (9600.0, 2048, 40, None), (9600.0, 1020, 2, None),
                                           (19200.0, 512, 5, 3), (9600.0, 28, 4, None)])
-def test_stream_block_kernel_shapes(oracle, fs, L, S, fixed):
+@pytest.mark.parametrize("carrier", [1, 0])
+def test_stream_block_kernel_shapes(oracle, fs, L, S, fixed, carrier):
     """the one-launch-per-block kernel on PCM streams block after block against the oracle's modem: CYCLES = 5 (a true division in
     the scan), blocks that are not whole 512-sample tiles, 16-symbol groups or 16-byte rows of PCM, an odd length, more streams,
     a block shorter than the filter, fixed timing; every block's index, symbols, costas_frame[], loop state"""
@@ -1006,6 +1007,7 @@ def test_stream_block_kernel_shapes(oracle, fs, L, S, fixed):
     kw = dict(timing_mode=mode, fixed_index=fixed) if fixed is not None else dict(timing_mode=mode)
     m = modem(fs=fs, rs=rs, frame_size=L, **kw)
     m.tune(stream_block=1)
+    m.tune(stream_carrier=carrier)      # 1: the streams' one carrier from the table (carrier.h), 0: every stream's own recurrence
     m.streams_reset(S, 1500.0)
     om = [oracle.modem(fs, rs, L, loop_bw=BW, **kw) for _ in range(S)]
     for o in om:
@@ -1441,10 +1443,10 @@ def test_streams_stretches_of_zero_symbols(oracle, block):
 
 
 def test_streams_leave_the_shared_carrier(oracle):
-    """the streams' one carrier (stream_scan_kernel's table, advanced a block ahead by a spare wave) handed back to the per-stream mixer
-    state when another kernel takes over: two blocks through the table, two through the kernels apart (mixer_kernel reads every
-    stream's own state), one through the one-launch-per-block kernel, two through stream_scan_kernel again (now with its mixer wave),
-    a reset, and the table again; every block against the oracle's modems"""
+    """the streams' one carrier (a table of the block's phases, advanced a block ahead by spare waves of stream_scan_kernel + the loop
+    kernel, or of stream_block_kernel) while the two kernels that use it alternate, then handed back to the per-stream mixer state when
+    the kernels apart take over (mixer_kernel reads every stream's own state), then the one-launch kernel and stream_scan_kernel on
+    per-stream state (its mixer wave), a reset, and the table again; every block against the oracle's modems"""
     fs, rs, L, S = 19200.0, 2400.0, 512, 21
     m = modem(fs=fs, rs=rs, frame_size=L)
     m.tune(stream_block=0)
@@ -1457,7 +1459,7 @@ def test_streams_leave_the_shared_carrier(oracle):
         om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
         for o in om:
             o.set_mixer_hz(1350.0)
-        for k, (scan, block) in enumerate([(1, 0), (1, 0), (0, 0), (0, 0), (0, 1), (1, 0), (1, 0)]):
+        for k, (scan, block) in enumerate([(1, 0), (0, 1), (1, 0), (1, 0), (0, 1), (0, 0), (0, 0), (0, 1), (1, 0), (1, 0)]):
             m.tune(stream_scan=scan)
             m.tune(stream_block=block)
             pcm = (7000 * rng.standard_normal((S, L))).astype(np.int16)
