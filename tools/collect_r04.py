@@ -138,9 +138,15 @@ def main():
     text("fir_fast", "fir", "qpsk_rrc_fir_batch on the config-2 block, 4096 x 16384 samples (tools/bench_fir_fast.py): per-launch event times (clocks not settled: see r04_power.txt for steady state).")
     text("dropin", "dropin_rx_frame", "The drop-in rx_frame() (examples/dropin_main.c through libqpsk_hip) against the reference's rx_frame() compiled here (tools/bench_dropin.py 3000).")
     text("config5", "config5", "BASELINE config 5 (tools/bench_config5.py).")
+    text("zero_stretches", "zero_stretches", "Stretches of exactly-zero symbols (costas_asm.h `ign`): tools/bench_streams_zero.py.  Before that change every group of a lane with such\n"
+         "symbols fell out of the Costas instruction stream into the C++ step, for its whole workgroup: the loop kernel of the first block after\n"
+         "qpsk_streams_reset() took 1.06 ms instead of 0.16-0.18 (round 3's and this round's first traces).")
     blocks = []
-    for name, label in (("streams", "4096 streams, the library's choice (mixer + filter + scan as one kernel)"), ("streams_apart", "4096 streams, QPSK_STREAM_SCAN=0 (mixer, filter, scan kernels apart)"),
-                        ("streams_2560", "2560 streams, the library's choice"), ("streams_2560_apart", "2560 streams, QPSK_STREAM_SCAN=0")):
+    for name, label in (("streams", "4096 streams, the library's choice (filter + scan as one kernel, the streams' one carrier from the table: carrier.h)"),
+                        ("streams_own_carrier", "4096 streams, QPSK_STREAM_CARRIER=0 (every stream's own carrier recurrence: the kernel's mixer wave)"),
+                        ("streams_apart", "4096 streams, QPSK_STREAM_SCAN=0 (mixer, filter, scan kernels apart)"),
+                        ("streams_1024", "1024 streams, the library's choice"), ("streams_1024_apart", "1024 streams, QPSK_STREAM_SCAN=0"),
+                        ("streams_2560", "2560 streams, the library's choice (before the carrier table)"), ("streams_2560_apart", "2560 streams, QPSK_STREAM_SCAN=0 (before the carrier table)")):
         p = os.path.join(SRC, name + ".log")
         if ok(name) and os.path.exists(p):
             blocks += [label + ":"] + ["  " + ln for ln in open(p).read().splitlines() if ln.startswith("streams")]
@@ -160,7 +166,7 @@ def main():
     if ok("stream_block_profile") and os.path.exists(p):
         body = [ln for ln in open(p).read().splitlines() if ln.startswith("wave")]
         open(os.path.join(OUT, "%s_stream_block.txt" % TAG), "w").write(
-            "stream_block_kernel, one stream, 512-sample blocks: shader cycles per phase of its two waves (s_memtime stamps, build -DQPSK_SBLK_PROF; the printf adds to the\n"
+            "stream_block_kernel, one stream, 512-sample blocks: shader cycles per phase of its waves (s_memtime stamps, build -DQPSK_SBLK_PROF; the printf adds to the\n"
             "wall time, the cycle counts are the kernel's), tools/bench_streams_host.py 1 60:\n\n" + "\n".join(body[-24:]) + "\n")
     # streams per call, from the kernel trace
     p = newest("prof_streams", "*kernel_trace.csv") if ok("prof_streams") else None

@@ -64,6 +64,29 @@ pmcrun pmc_fetch_streams FETCH_SIZE python3 tools/loop_kernel.py streams 0 4096 
 pmcrun pmc_write_streams WRITE_SIZE python3 tools/loop_kernel.py streams 0 4096 8
 txt power_streams python3 tools/power_probe.py --cmd "python3 tools/loop_kernel.py streams 6"
 fi
+if [[ $part == *f* ]]; then      # after the streams' one carrier (carrier.h) and the zero-symbol stretches: bench lines, streams, drop-in
+run bench python3 bench.py
+run bench20 python3 bench.py --steps 20 --warmup 5
+run bench8192 python3 bench.py --frames 8192 --cpu-frames 0 --no-shard
+prof prof_bench python3 bench.py --cpu-frames 0
+prof prof_bench20 python3 bench.py --steps 20 --warmup 5 --cpu-frames 0 --no-shard --no-timing-modes
+prof prof_streams python3 tools/bench_streams.py
+txt streams python3 tools/bench_streams.py
+QPSK_STREAM_CARRIER=0 txt streams_own_carrier python3 tools/bench_streams.py
+QPSK_STREAM_SCAN=0 txt streams_apart python3 tools/bench_streams.py
+txt streams_1024 python3 tools/bench_streams.py --streams 1024
+QPSK_STREAM_SCAN=0 txt streams_1024_apart python3 tools/bench_streams.py --streams 1024
+pmcrun pmc_fetch_streams FETCH_SIZE python3 tools/loop_kernel.py streams 0 4096 8
+pmcrun pmc_write_streams WRITE_SIZE python3 tools/loop_kernel.py streams 0 4096 8
+txt power_streams python3 tools/power_probe.py --cmd "python3 tools/loop_kernel.py streams 6"
+txt dropin python3 tools/bench_dropin.py 3000
+txt streams_host_1 python3 tools/bench_streams_host.py 1 3000
+txt streams_host_8 python3 tools/bench_streams_host.py 8 2000
+txt streams_host_64 python3 tools/bench_streams_host.py 64 1000
+txt zero_stretches python3 tools/bench_streams_zero.py
+make -C qpsk_amd/csrc VARIANT=sbprof EXTRA=-DQPSK_SBLK_PROF > $O/sbprof_build.log 2>&1 && QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_sbprof.so txt stream_block_profile python3 tools/bench_streams_host.py 1 60
+rm -f qpsk_amd/libqpsk_hip_sbprof.so
+fi
 # what travels back is capped at 64 MiB: keep the summaries, drop the per-launch traces except the streams' (per-call table) and rocprofv3's databases
 find $O -name "*kernel_trace.csv" ! -path "*prof_streams*" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*.db" -delete; du -sh $O | tail -1
 ls $O/*.failed 2>/dev/null; cut -c1-300 $O/bench.json 2>/dev/null
