@@ -505,7 +505,7 @@ def main():
     if world == 1 and (args.frames, L) == (FRAMES_1GPU, 16384) and not args.no_streams:
         # SURVEY 8(f) N1, the reference's real input and call pattern (qpsk.c:88, 344-354), measured beside the headline and NOT part of it:
         #  (a) 4096 running streams, one 16384-sample int16 PCM block each per call (PCM from the library's own transmit chain at +50 Hz):
-        #      mixer + rrc_fir() + histogram timing in one kernel, then the loop kernel; ms per block = median of blocks 2..7, an event pair
+        #      mix + rrc_fir() + histogram timing in one kernel, then the loop kernel; ms per block = median of blocks 2..7, an event pair
         #      and a synchronisation around every call;
         #  (b) ONE stream, one 512-sample block per call through host buffers (the shipped FS 9600 / RS 2400 / FRAME_SIZE 512): the
         #      drop-in rx_frame()'s path, wall time per call.
@@ -534,7 +534,8 @@ def main():
             if k == 2:
                 o_last = {kk: vv[0].cpu().numpy() for kk, vv in o_.items() if vv is not None}
         ms_.sync()
-        st = {"streams": S_, "block_samples": L, "timing": "histogram (qpsk.c:127-180)", "kernels": "stream_scan_kernel + costas_pipe_kernel",
+        st = {"streams": S_, "block_samples": L, "timing": "histogram (qpsk.c:127-180)", "kernels": ms_.last_kernel(),
+              "carrier": "one carrier for all streams (what qpsk_streams_reset() sets up): the block's phases from a table run a block ahead by spare waves",
               "pcm_block_ms": float(np.median(tms[2:])), "pcm_msamples_per_s": S_ * L / (float(np.median(tms[2:])) * 1e-3) / 1e6,
               "first_blocks_ms": [float(t) for t in tms[:2]]}
         if not args.no_parity:      # stream 0, blocks 0..2, against the oracle's modem (state carried)
