@@ -146,3 +146,36 @@ def test_bit_stages_match_reference(oracle):
         assert ref.crc16(d.tobytes()) == oracle.crc16(d.tobytes())
     s = rng.integers(0, 4, size=300).astype(np.uint8)
     assert bits_equal(ref.scramble_stream(s, 0), oracle.scramble_stream(s))
+
+
+@pytest.mark.parametrize("name", ["shipped", "c1small"])
+def test_zero_symbols_and_signed_zero_states_match_reference(oracle, name):
+    """Exactly-zero symbols (the first block after start-up, silent PCM) meeting loop states where the sign of a zero decides
+    (costas_loop.c:44-59: sgn(0) = -1, x + -0): the oracle against the reference itself, state loaded through the reference's own
+    set_phase() / set_frequency().  The HIP path's handling of such stretches (costas_asm.h `ign`, costas_step_t's exact-zero branch) is
+    tested against the oracle on the GPU (test_streams_stretches_of_zero_symbols); this pins the oracle there."""
+    nz = np.float32(-0.0)
+    states = [(0.0, 0.0), (nz, 0.0), (0.0, nz), (nz, nz), (1.0, 0.0), (2.5, nz), (-2.5, nz), (4.0, 0.0), (5.5, nz), (-4.0, 0.0), (-5.5, nz),
+              (0.3, 0.7), (-1.0, -0.9), (6.0, 0.99), (0.0, 1e-30), (6.2831855, 0.0), (-6.2831855, nz), (1.5707964, 0.0), (3.1415927, nz),
+              (nz, -1e-42)]
+    rng = np.random.default_rng(5)
+    for ph, fr in states:
+        ref = Reference(name)
+        ref.reset(BW, -1.0, 1.0, .35, 1550.0, 1500.0)
+        ref.lib.set_phase(float(ph))
+        ref.lib.set_frequency(float(fr))
+        L = ref.frame_size
+        m = oracle.modem(ref.fs, ref.rs, L, loop_bw=BW)
+        m.set_mixer(ref.mixer)
+        m.s.loop.phase = float(ph)
+        m.s.loop.freq = float(fr)
+        for k in range(6):
+            blk = np.zeros(L, np.int16) if k in (0, 2, 3, 4) else (6000 * rng.standard_normal(L)).astype(np.int16)
+            ref.rx_pcm(blk)
+            m.rx_pcm(blk)
+            assert bits_equal(ref.costas_frame, m.costas_frame) and bits_equal(ref.symbols, m.symbols), (ph, fr, k)
+            assert ref.phase.tobytes() == m.phase.tobytes() and ref.freq.tobytes() == m.freq.tobytes(), (ph, fr, k)
+            if ref.cycles < 8:      # SURVEY Q5, as in test_streaming_pcm_matches_reference: the reference's last pick may lie past its array
+                d = ref.decimated
+                d[2 * ref.nsym - 1] = m.decimated[2 * ref.nsym - 1]
+                ref.set_decimated(d)
