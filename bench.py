@@ -393,7 +393,10 @@ def main():
         "config": {"workload": "batch %d frames x %d complex samples per GPU, 2400 baud, 8x oversample, fused RRC FIR + Costas + slicer, fixed timing offset %d (%s)" % (
                        F, L, FIXED_INDEX, "BASELINE configs[1]" if (F, L) == (4096, 16384) else
                        "BASELINE configs[3] per-GPU share" if (F, L) == (8192, 16384) else "non-BASELINE shape"),
-                   "frames_per_gpu": F, "frames_total": world * F, "gpus_visible_per_rank_box": ndev, "frame_size": L, "fs": FS, "rs": RS, "loop_bw": "TAU/100", "sharding": "independent frames per GPU, no collective"},
+                   "frames_per_gpu": F, "frames_total": world * F, "gpus_visible_per_rank_box": ndev, "frame_size": L, "fs": FS, "rs": RS, "loop_bw": "TAU/100", "sharding": "independent frames per GPU, no collective",
+                   # N = 1 is quoted on BASELINE configs[1] (4096 frames), N > 1 on configs[3]'s per-GPU share (8192 frames each): the single-GPU
+                   # rate at THAT shape is the N = 1 line's shard_8192 key, the like-for-like base of a scaling curve
+                   "single_gpu_rate_at_this_shape": ("this line's value" if world == 1 else "the N = 1 line's shard_8192.msamples_per_s")},
         "roofline": rl,
         "library": {"path": os.path.relpath(lib_file, ROOT) if lib_file.startswith(ROOT) else lib_file,
                     "sha256": hashlib.sha256(open(lib_file, "rb").read()).hexdigest(),
