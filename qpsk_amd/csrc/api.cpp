@@ -1100,6 +1100,8 @@ static int streams_from_filter(qpsk_ctx *c, const float *d_in, bool filtered, ui
     }
     /* qpsk.c:127-180 (scanned: stream_scan_kernel has left the index, and the filtered block planar by decimation phase) */
     if (scanned) {
+        /* fixed timing rides on the same kernel (its scan waves have slack; their index is simply replaced) */
+        if (c->prm.timing_mode == QPSK_TIMING_FIXED) KERNEL_TRY(launch_fill_i32(idx, n, c->prm.fixed_index, c->stream));
     } else if (c->prm.timing_mode == QPSK_TIMING_HIST)
         KERNEL_TRY(launch_timing_hist(filt, n, L, c->cycles, idx, nullptr, tuned(c->tune.hist_generic, 0) == 2, c->stream));
     else if (c->prm.timing_mode == QPSK_TIMING_FIXED)
@@ -1131,7 +1133,7 @@ static bool stream_scan_ok(const qpsk_ctx *c, bool pcm, bool shared_carrier)
      * 2048, 0.76 against 1.00 at 2560 (profiles/r04_streams_carrier.txt) */
     const int from = pcm ? (shared_carrier ? 1024 : 2560) : 3584;
     return c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0 && tuned(c->tune.generic, 0) == 0 && c->cycles == 8 &&
-           c->prm.timing_mode == QPSK_TIMING_HIST && c->prm.frame_size % stream_scan_tile() == 0 &&
+           (c->prm.timing_mode == QPSK_TIMING_HIST || c->prm.timing_mode == QPSK_TIMING_FIXED) && c->prm.frame_size % stream_scan_tile() == 0 &&
            tuned(c->tune.stream_scan, c->nstreams >= from ? 1 : 0) != 0;
 }
 

@@ -1027,23 +1027,25 @@ def test_stream_block_kernel_shapes(oracle, fs, L, S, fixed, carrier):
             assert cpu(o["phase"])[s_] == om[s_].phase and cpu(o["freq"])[s_] == om[s_].freq, (k, s_)
 
 
+@pytest.mark.parametrize("fixed", [None, 5])
 @pytest.mark.parametrize("carrier", [1, 0])
 @pytest.mark.parametrize("L,S", [(2048, 47), (256, 33), (1024, 16), (4096, 5)])
-def test_streams_pcm_mixer_filter_and_scan_in_one_kernel(oracle, L, S, carrier):
+def test_streams_pcm_mixer_filter_and_scan_in_one_kernel(oracle, L, S, carrier, fixed):
     """stream_scan_kernel (PCM in; the scan fed from LDS, the filtered block left planar by decimation phase for the loop kernel's
     picks) block after block against the oracle's modems: several workgroups and a ragged last one, one to sixteen tiles per block,
     state carried through five blocks (delay lines, carrier phase, loop, picks), an all-zero block; and equal to the four kernels
     apart bit for bit.  carrier = 1: the streams' ONE carrier from the table the block before left (a spare wave of workgroup 0 runs
     the next block's); 0: the carrier recurrences of a workgroup's 16 streams by its mixer wave, a tile ahead of its filter waves"""
     fs, rs = 19200.0, 2400.0
-    m = modem(fs=fs, rs=rs, frame_size=L)
-    m2 = modem(fs=fs, rs=rs, frame_size=L)
+    kw = dict(timing_mode=TIMING_FIXED, fixed_index=fixed) if fixed is not None else {}      # fixed timing rides on the same kernel
+    m = modem(fs=fs, rs=rs, frame_size=L, **kw)
+    m2 = modem(fs=fs, rs=rs, frame_size=L, **kw)
     for mm, scan in ((m, 1), (m2, 0)):
         mm.tune(stream_block=0)
         mm.tune(stream_scan=scan)
         mm.tune(stream_carrier=carrier)
         mm.streams_reset(S, 1500.0)
-    om = [oracle.modem(fs, rs, L, loop_bw=BW) for _ in range(S)]
+    om = [oracle.modem(fs, rs, L, loop_bw=BW, **kw) for _ in range(S)]
     for o in om:
         o.set_mixer_hz(1500.0)
     rng = np.random.default_rng(L + S)

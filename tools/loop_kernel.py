@@ -6,6 +6,7 @@
           fft_est (qpsk_timing_fft_bin_batch)           scan (qpsk_timing_scan_batch)
           config2 / config3 / hist (qpsk_rx_batch in the three timing modes)
           streams (qpsk_streams_rx_pcm: one 16384-sample PCM block of `frames` running streams per call, histogram timing)
+          streams_fixed (the same with the fixed timing offset)
 """
 import os
 import sys
@@ -23,6 +24,8 @@ F = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 per = int(sys.argv[4]) if len(sys.argv) > 4 else 200      # launches between two synchronisations (counter passes: a handful, with secs = 0)
 dev = torch.device("cuda", 0)
 mode = {"config3": qpsk_amd.TIMING_FFT, "fft_est": qpsk_amd.TIMING_FFT, "hist": qpsk_amd.TIMING_HIST, "streams": qpsk_amd.TIMING_HIST}.get(what, qpsk_amd.TIMING_FIXED)
+if what == "streams_fixed":
+    what = "streams"
 m = qpsk_amd.Modem(fs=bench.FS, rs=bench.RS, frame_size=bench.L, timing_mode=mode, fixed_index=bench.FIXED_INDEX)
 if what == "fir_generic":
     m.tune(fir_generic=1)
