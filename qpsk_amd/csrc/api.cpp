@@ -942,7 +942,7 @@ int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, i
 
 /* --------------------------------------------------------------- streams */
 static bool stream_scan_ok(const qpsk_ctx *c, bool pcm, bool shared_carrier);
-static bool stream_block_ok(const qpsk_ctx *c);
+static bool stream_block_ok(const qpsk_ctx *c, bool pcm = true);
 
 int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
 {
@@ -1018,14 +1018,23 @@ int qpsk_streams_get_loop_state(qpsk_ctx *c, float *h_state)
 
 /* One launch per block (streamblock.hip) instead of the five-kernel composition: few, short streams -- the reference's call
  * pattern, where the launches are the cost.  Histogram or fixed timing (the FFT estimate keeps its own kernel). */
-static bool stream_block_ok(const qpsk_ctx *c)
+static bool stream_block_ok(const qpsk_ctx *c, bool pcm)
 {
     const int t = tuned(c->tune.stream_block, -1);
     if (t == 0 || c->prm.timing_mode == QPSK_TIMING_FFT || c->prm.frame_size > stream_block_max_frame() ||
         c->nsym * c->cycles > c->prm.frame_size || tuned(c->tune.generic, 0) != 0 ||
         stream_block_lds_bytes(c->prm.frame_size, c->nsym) > (size_t)MAX_LDS_BYTES)
         return false;
-    return t == 1 || c->nstreams <= 1024;
+    /* [measured, profiles/r04_streams_short_blocks.txt: PCM streams back to back] the kernels apart cost 70 us (512-sample blocks) to
+     * 220 us (2048) whatever the count -- launches and serial chains -- and this kernel ~17 us + 13.5 ns per 512 samples of a stream:
+     * it wins up to ~4 M samples per block of all streams (7800 x 512, 4400 x 1024, 2400 x 2048).  Complex input: round 4's first rule */
+    return t == 1 || (pcm ? (long long)c->nstreams * c->prm.frame_size <= 3500000LL : c->nstreams <= 1024);
+}
+
+/* PCM streams that both stream_scan_kernel and the one-launch kernel would take: which of the two */
+static bool prefer_stream_scan(const qpsk_ctx *c, bool scan_ok)
+{
+    return scan_ok && tuned(c->tune.stream_block, -1) != 1;
 }
 
 /* pcm / cplx: exactly one of them; every pointer device-visible (device memory or mapped pinned host memory) */
@@ -1132,9 +1141,16 @@ static bool stream_scan_ok(const qpsk_ctx *c, bool pcm, bool shared_carrier)
      * (MODE 2: no mixer wave, no mixer kernel) PCM input pays from 1024 streams on: 0.73 against 0.79 ms there, 0.75 against 0.93 at
      * 2048, 0.76 against 1.00 at 2560 (profiles/r04_streams_carrier.txt) */
     const int from = pcm ? (shared_carrier ? 1024 : 2560) : 3584;
+    bool wanted = c->nstreams >= from;
+    /* short blocks (the one-launch kernel's range), shared carrier: a workgroup's time shrinks with the block, so the kernel pays from
+     * ~1.4 M samples per block of all streams on -- 106.7 us against 151.9 (one launch per block) and 117.1 (kernels apart) at
+     * 1024 x 2048, 61.8 against 95.9 and 80.6 at 2048 x 1024, 41.7 against 71.7 and 61.8 at 4096 x 512; below that the one-launch
+     * kernel is ahead (profiles/r04_streams_short_blocks.txt) */
+    if (pcm && shared_carrier && c->prm.frame_size <= stream_block_max_frame())
+        wanted = (long long)c->nstreams * c->prm.frame_size >= 1400000LL && c->nstreams >= 256;
     return c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0 && tuned(c->tune.generic, 0) == 0 && c->cycles == 8 &&
            (c->prm.timing_mode == QPSK_TIMING_HIST || c->prm.timing_mode == QPSK_TIMING_FIXED) && c->prm.frame_size % stream_scan_tile() == 0 &&
-           tuned(c->tune.stream_scan, c->nstreams >= from ? 1 : 0) != 0;
+           tuned(c->tune.stream_scan, wanted ? 1 : 0) != 0;
 }
 
 static int streams_scanned(qpsk_ctx *c, const int16_t *d_pcm, const float *d_cplx, uint8_t *d_sym, float *d_freq, float *d_phase,
@@ -1174,7 +1190,7 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
     if (!c || !d_in) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_cplx: null argument");
     if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
     if (bind(c)) return QPSK_ERR_HIP;
-    if (d_sym && stream_block_ok(c)) {
+    if (d_sym && stream_block_ok(c, false)) {
         if (int rb = streams_block_launch(c, nullptr, d_in, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
         return streams_copy_loop(c, d_freq, d_phase);
     }
@@ -1189,12 +1205,13 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
     if (!c || !d_pcm) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_pcm: null argument");
     if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
     if (bind(c)) return QPSK_ERR_HIP;
-    if (d_sym && stream_block_ok(c)) {
+    const bool scan = stream_scan_ok(c, true, c->carrier_shared && tuned(c->tune.stream_carrier, 1) != 0) && ((uintptr_t)d_pcm % 4) == 0;
+    if (d_sym && stream_block_ok(c) && !prefer_stream_scan(c, scan)) {
         if (int rb = streams_block_launch(c, d_pcm, nullptr, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
         return streams_copy_loop(c, d_freq, d_phase);
     }
     const int n = c->nstreams, L = c->prm.frame_size;
-    if (stream_scan_ok(c, true, c->carrier_shared && tuned(c->tune.stream_carrier, 1) != 0) && ((uintptr_t)d_pcm % 4) == 0)
+    if (scan)
         return streams_scanned(c, d_pcm, nullptr, d_sym, d_freq, d_phase, d_costas, d_index);
     int rc = ensure(c, c->mixed, sizeof(float) * 2 * (size_t)n * L);
     if (rc) return rc;
@@ -1239,7 +1256,7 @@ int qpsk_streams_rx_pcm_host(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io
     }
     if (h_loop_io) memcpy(c->h_stage + o_loop, h_loop_io, 8 * n);
     memcpy(c->h_stage + o_pcm, h_pcm, 2 * n * L);
-    if (stream_block_ok(c)) {
+    if (stream_block_ok(c) && !prefer_stream_scan(c, stream_scan_ok(c, true, c->carrier_shared && tuned(c->tune.stream_carrier, 1) != 0))) {
         /* one launch, no copy engine: the kernel reads the PCM (and the loop state) from the pinned staging buffer and leaves its
          * results there -- a kilobyte in, a few hundred bytes out per stream */
         unsigned char *m = nullptr;
