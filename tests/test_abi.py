@@ -184,3 +184,33 @@ def test_streams_rx_pcm_host_equals_the_device_pointer_calls(oracle, block):
             assert bad.size == 0, "block %d stream %d: costas_frame differs at symbols %s: %s vs %s" % (
                 k, i, bad[:8], cos[i][bad[:4]], o.costas_frame[bad[:4]])
             assert st[i, 0] == o.phase and st[i, 1] == o.freq, (k, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs,L,S", [(9600.0, 512, 1500), (19200.0, 512, 3000)])
+def test_streams_rx_pcm_host_many_streams(oracle, fs, L, S):
+    """the host-buffer call with the library's own kernel choice at stream counts beyond the handful the drop-in uses: 1500 streams at
+    the shipped configuration (one launch per block reading the pinned staging buffer) and 3000 at CYCLES = 8 (staged copy, then
+    stream_scan_kernel + the loop kernel); a sample of streams against the oracle's modems, block after block"""
+    import numpy as np
+    import qpsk_amd
+    from sigutil import bits_equal
+    rs, B = 2400.0, 3
+    m = qpsk_amd.Modem(fs=fs, rs=rs, frame_size=L)
+    m.streams_reset(S, 1500.0)
+    rng = np.random.default_rng(S)
+    check = [0, 7, S // 2, S - 1]
+    om = {i: oracle.modem(fs, rs, L, loop_bw=np.float32(2.0 * 3.14159265358979323846 / 100.0)) for i in check}
+    for o in om.values():
+        o.set_mixer_hz(1500.0)
+    N = m.nsym
+    for k in range(B):
+        pcm = (6000 * rng.standard_normal((S, L))).astype(np.int16)
+        sym = np.zeros((S, N), np.uint8); cos = np.zeros((S, N, 2), np.float32); idx = np.zeros(S, np.int32)
+        rc = m.L.qpsk_streams_rx_pcm_host(m.h, C.c_void_p(pcm.ctypes.data), None, C.c_void_p(sym.ctypes.data),
+                                          C.c_void_p(cos.ctypes.data), C.c_void_p(idx.ctypes.data))
+        assert rc == 0, m.L.qpsk_last_error()
+        for i, o in om.items():
+            o.rx_pcm(pcm[i])
+            assert idx[i] == o.index and bits_equal(sym[i], o.symbols) and bits_equal(cos[i], o.costas_frame), (k, i)
+    assert m.last_kernel() == ("stream_block_kernel" if fs == 9600.0 else "stream_scan_kernel + costas_pipe_kernel")
