@@ -1148,7 +1148,7 @@ static bool stream_scan_ok(const qpsk_ctx *c, bool pcm, bool shared_carrier)
      * kernel is ahead (profiles/r04_streams_short_blocks.txt) */
     if (pcm && shared_carrier && c->prm.frame_size <= stream_block_max_frame())
         wanted = (long long)c->nstreams * c->prm.frame_size >= 1400000LL && c->nstreams >= 256;
-    return c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0 && tuned(c->tune.generic, 0) == 0 && c->cycles == 8 &&
+    return c->taps_symmetric && tuned(c->tune.fir_generic, 0) == 0 && tuned(c->tune.generic, 0) == 0 && (c->cycles == 8 || c->cycles == 4) &&
            (c->prm.timing_mode == QPSK_TIMING_HIST || c->prm.timing_mode == QPSK_TIMING_FIXED) && c->prm.frame_size % stream_scan_tile() == 0 &&
            tuned(c->tune.stream_scan, wanted ? 1 : 0) != 0;
 }
@@ -1174,7 +1174,7 @@ static int streams_scanned(qpsk_ctx *c, const int16_t *d_pcm, const float *d_cpl
         }
     }
     KERNEL_TRY(launch_stream_scan(d_pcm, d_cplx, c->s_mixer, c->s_memory, (float *)c->filtered.p, c->d_taps, (int32_t *)c->index.p, n, L,
-                                  c->d_status, c->stream, ctab, ctab_next, c->s_cstate, ctab ? (int)c->carrier_scans++ : 0));
+                                  c->d_status, c->stream, ctab, ctab_next, c->s_cstate, ctab ? (int)c->carrier_scans++ : 0, c->cycles));
     const int rc = streams_from_filter(c, nullptr, true, d_sym, d_freq, d_phase, d_costas, d_index, true);
     if (c->carrier_pending) {      /* the loop kernel was never reached: the table is finished all the same */
         float *tab = c->carrier_pending;

@@ -170,13 +170,13 @@ int stream_block_max_frame(void);
 int prepare_stream_block(void);
 int launch_stream_block(const StreamBlockArgs &a, int nstreams, hipStream_t s, const StreamBlockInline *inl = nullptr);   /* inl: PCM and, if
                         a.loop_in is set (to anything), the loop state come from *inl instead of a.pcm / a.loop_in */
-/* streamscan.hip: PCM -> mix -> rrc_fir() -> histogram timing of running streams in one kernel (CYCLES = 8, frame_size %
- * stream_scan_tile() == 0, symmetric taps); yout [n][8][frame_size / 8] planar by decimation phase; updates mixer [n][4], memory [n][127] */
+/* streamscan.hip: PCM -> mix -> rrc_fir() -> histogram timing of running streams in one kernel (CYCLES = 8 or 4, frame_size %
+ * stream_scan_tile() == 0, symmetric taps); yout [n][cycles][frame_size / cycles] planar by decimation phase; updates mixer [n][4], memory [n][127] */
 int stream_scan_tile(void);
 int prepare_stream_scan(void);
 int launch_stream_scan(const int16_t *pcm, const float *x, float *mixer, float *memory, float *yout, const float *taps, int32_t *index,
                        int nstreams, int frame_size, int *status, hipStream_t s, const float *ctab = nullptr, float *ctab_next = nullptr,
-                       float *cstate = nullptr, int cseq = 0);
+                       float *cstate = nullptr, int cseq = 0, int cycles = 8);
 /* the shared carrier of MODE 2 (streamscan.hip): cstate [8] = {phase the next table starts from, fbb_rx_rect, phase the last table
  * started from, the relay counter of stream_scan_kernel's spare waves (an int: zero it with cseq = 0), unused}; a table = the frame_size
  * phases of one block; cseq = the number of MODE 2 launches since that counter was zeroed.  ctab != NULL selects MODE 2: this block's phases from ctab,

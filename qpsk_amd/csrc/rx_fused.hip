@@ -589,8 +589,13 @@ costas_pipe_kernel(FusedArgs a, int *status)
             for (int r = 0; r < R; r++) {
                 const int i = c * S + R * q + r, s = i * a.cycles + ix;
                 if (i < N) {
-                    if (a.refill_planar) row[i] = blk[(size_t)ix * N + i];      /* the block planar by decimation phase (streamscan.hip): [phase][symbol] */
-                    else row[i] = s < a.frame_size ? blk[s] : make_float2(0.0f, 0.0f);
+                    if (a.refill_planar) {      /* the block planar by decimation phase (streamscan.hip): [cycles][symbols]; an index of
+                                                  * CYCLES or more (the histogram has 8 bins whatever CYCLES is) reaches into the next symbol */
+                        const int pl = ix % a.cycles, sy = i + ix / a.cycles;
+                        row[i] = sy < N ? blk[(size_t)pl * N + sy] : make_float2(0.0f, 0.0f);
+                    } else {
+                        row[i] = s < a.frame_size ? blk[s] : make_float2(0.0f, 0.0f);
+                    }
                 }
             }
         }

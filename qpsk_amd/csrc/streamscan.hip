@@ -24,7 +24,7 @@
  * While all streams share ONE carrier (the state qpsk_streams_reset() leaves, and the carrier does not depend on the data) wave 12 has
  * nothing to do per workgroup: the block's phases come from a table the call before prepared (MODE 2 below, carrier.h).
  *
- * Served (host-checked): CYCLES = 8, frame_size a multiple of 256, symmetric taps, 4-byte aligned PCM rows, 16-byte aligned output.
+ * Served (host-checked): CYCLES = 8 or 4 (the description above is for 8; at 4 a lane's 8 outputs are two symbols), frame_size a multiple of 256, symmetric taps, 4-byte aligned PCM rows, 16-byte aligned output.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -114,7 +114,7 @@ template <int MODE>
 __global__ void __launch_bounds__(MODE ? sscan::THREADS : sscan::THREADS - 64)
 stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x, float *mixer, float2 *memory, float2 *__restrict__ yout,
                    const float *__restrict__ taps_g, int32_t *index, int nstreams, int frame_size, int *status,
-                   const float2 *__restrict__ ctab, float2 *ctab_next, float *cstate, int cseq)
+                   const float2 *__restrict__ ctab, float2 *ctab_next, float *cstate, int cseq, int cycles)
 {
     using namespace sscan;
     constexpr bool PCM = MODE != 0;
@@ -126,7 +126,9 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f0 = blockIdx.x * G;
-    const int ntiles = frame_size / TILE, nsym = frame_size / R;
+    /* CYCLES = 8 (a lane's 8 outputs are one symbol) or 4 (the reference's shipped rates: two symbols): the filter is the same; the
+     * scan's symbols, the planes of the filtered block and the symbol count differ */
+    const int ntiles = frame_size / TILE, nsym = frame_size / cycles;
 
     if (tid < NFIR) { sm->ready[tid] = 0; sm->mcons[tid] = 0; }
     if (tid < NSCAN) sm->consumed[tid] = 0;
@@ -230,15 +232,27 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
             ok = wait_ge(&sm->ready[g >> 1], t + 1, &sm->abort_flag);
             if (!__all(ok)) { ok = false; break; }
             const float4 *row = reinterpret_cast<const float4 *>(ring + ((size_t)(g * DRO + (t % DRO)) * 2 + comp) * PITCH);
+            if (cycles == 8) {
 #pragma unroll 4
-            for (int s = 0; s < TILE / 8; s++) {
-                const float4 a = row[2 * s], b = row[2 * s + 1];
-                av += fabsf(a.x); av += fabsf(a.y); av += fabsf(a.z); av += fabsf(a.w);      /* qpsk.c:131-136 */
-                av += fabsf(b.x); av += fabsf(b.y); av += fabsf(b.z); av += fabsf(b.w);
-                av *= 0.125f;                           /* av /= CYCLES (qpsk.c:137-138) */
-                if (av > mx) mx = av;                   /* qpsk.c:140-145 */
-                const float th = (mx * 0.125f) * qf;    /* (max / 8.0f) * q, qpsk.c:147-165 */
-                cum += (av <= th) ? 0 : 1;
+                for (int s = 0; s < TILE / 8; s++) {
+                    const float4 a = row[2 * s], b = row[2 * s + 1];
+                    av += fabsf(a.x); av += fabsf(a.y); av += fabsf(a.z); av += fabsf(a.w);      /* qpsk.c:131-136 */
+                    av += fabsf(b.x); av += fabsf(b.y); av += fabsf(b.z); av += fabsf(b.w);
+                    av *= 0.125f;                           /* av /= CYCLES (qpsk.c:137-138) */
+                    if (av > mx) mx = av;                   /* qpsk.c:140-145 */
+                    const float th = (mx * 0.125f) * qf;    /* (max / 8.0f) * q, qpsk.c:147-165 */
+                    cum += (av <= th) ? 0 : 1;
+                }
+            } else {      /* CYCLES = 4: four samples per symbol, / 4 is * 0.25 exactly; the histogram keeps its 8 bins (qpsk.c:130) */
+#pragma unroll 4
+                for (int s = 0; s < TILE / 4; s++) {
+                    const float4 a = row[s];
+                    av += fabsf(a.x); av += fabsf(a.y); av += fabsf(a.z); av += fabsf(a.w);
+                    av *= 0.25f;
+                    if (av > mx) mx = av;
+                    const float th = (mx * 0.125f) * qf;
+                    cum += (av <= th) ? 0 : 1;
+                }
             }
             if (lane == 0) publish(&sm->consumed[wave], t + 1);
         }
@@ -246,7 +260,7 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
             if (lane == 0) __hip_atomic_store(status, STATUS_PIPE_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
-        if (q == 0) cum = frame_size / 8;
+        if (q == 0) cum = frame_size / cycles;
         int h = __shfl_up(cum, 1) - cum;
         if (q == 0) h = 0;
         h += __shfl_xor(h, 8);
@@ -372,9 +386,17 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
                      y4 = fir_gain(make_float2(a4.x, a4.y)), y5 = fir_gain(make_float2(a5.x, a5.y)),
                      y6 = fir_gain(make_float2(a6.x, a6.y)), y7 = fir_gain(make_float2(a7.x, a7.y));
         if (fv[fl]) {      /* the filtered block, planar by decimation phase: [stream][phase][symbol] */
-            float2 *o = yout + ((size_t)(f0 + g) * R) * nsym + (size_t)t * QL + q;
-            o[0 * (size_t)nsym] = y0; o[1 * (size_t)nsym] = y1; o[2 * (size_t)nsym] = y2; o[3 * (size_t)nsym] = y3;
-            o[4 * (size_t)nsym] = y4; o[5 * (size_t)nsym] = y5; o[6 * (size_t)nsym] = y6; o[7 * (size_t)nsym] = y7;
+            if (cycles == 8) {
+                float2 *o = yout + ((size_t)(f0 + g) * R) * nsym + (size_t)t * QL + q;
+                o[0 * (size_t)nsym] = y0; o[1 * (size_t)nsym] = y1; o[2 * (size_t)nsym] = y2; o[3 * (size_t)nsym] = y3;
+                o[4 * (size_t)nsym] = y4; o[5 * (size_t)nsym] = y5; o[6 * (size_t)nsym] = y6; o[7 * (size_t)nsym] = y7;
+            } else {      /* four planes of frame_size / 4 symbols; the lane's two symbols sit side by side in each: 16-byte stores */
+                float2 *o = yout + (size_t)(f0 + g) * frame_size + (size_t)t * (2 * QL) + 2 * q;
+                *reinterpret_cast<float4 *>(o + 0 * (size_t)nsym) = make_float4(y0.x, y0.y, y4.x, y4.y);
+                *reinterpret_cast<float4 *>(o + 1 * (size_t)nsym) = make_float4(y1.x, y1.y, y5.x, y5.y);
+                *reinterpret_cast<float4 *>(o + 2 * (size_t)nsym) = make_float4(y2.x, y2.y, y6.x, y6.y);
+                *reinterpret_cast<float4 *>(o + 3 * (size_t)nsym) = make_float4(y3.x, y3.y, y7.x, y7.y);
+            }
         }
         float *pi = ring + ((size_t)(g * DRO + (t % DRO)) * 2 + 0) * PITCH + R * q;
         float *pq = pi + PITCH;
@@ -413,12 +435,13 @@ int launch_carrier_broadcast(const float *cstate, float *mixer, int nstreams, hi
 }
 
 /* CYCLES = 8, frame_size % 256 == 0, symmetric taps, 16-byte aligned yout (the caller checks); exactly one of pcm (4-byte aligned rows;
- * mixer state updated) and x (16-byte aligned complex blocks); yout [nstreams][8][frame_size / 8] */
+ * mixer state updated) and x (16-byte aligned complex blocks); yout [nstreams][cycles][frame_size / cycles], cycles 8 or 4 */
 int launch_stream_scan(const int16_t *pcm, const float *x, float *mixer, float *memory, float *yout, const float *taps, int32_t *index,
-                       int nstreams, int frame_size, int *status, hipStream_t s, const float *ctab, float *ctab_next, float *cstate, int cseq)
+                       int nstreams, int frame_size, int *status, hipStream_t s, const float *ctab, float *ctab_next, float *cstate, int cseq,
+                       int cycles)
 {
     using namespace sscan;
-    if (frame_size % TILE != 0 || (pcm != nullptr) == (x != nullptr) || (reinterpret_cast<uintptr_t>(pcm) & 3) != 0 ||
+    if (frame_size % TILE != 0 || (cycles != 8 && cycles != 4) || (pcm != nullptr) == (x != nullptr) || (reinterpret_cast<uintptr_t>(pcm) & 3) != 0 ||
         (reinterpret_cast<uintptr_t>(x) & 15) != 0 || (reinterpret_cast<uintptr_t>(yout) & 15) != 0 ||
         (reinterpret_cast<uintptr_t>(ctab) & 15) != 0 || (reinterpret_cast<uintptr_t>(ctab_next) & 15) != 0 ||
         (ctab != nullptr && (!pcm || !ctab_next || !cstate)))
@@ -427,14 +450,14 @@ int launch_stream_scan(const int16_t *pcm, const float *x, float *mixer, float *
     if (pcm && ctab)
         hipLaunchKernelGGL(stream_scan_kernel<2>, grid, dim3(THREADS), LDS_BYTES, s, pcm, nullptr, mixer, reinterpret_cast<float2 *>(memory),
                            reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status,
-                           reinterpret_cast<const float2 *>(ctab), reinterpret_cast<float2 *>(ctab_next), cstate, cseq);
+                           reinterpret_cast<const float2 *>(ctab), reinterpret_cast<float2 *>(ctab_next), cstate, cseq, cycles);
     else if (pcm)
         hipLaunchKernelGGL(stream_scan_kernel<1>, grid, dim3(THREADS), LDS_BYTES, s, pcm, nullptr, mixer, reinterpret_cast<float2 *>(memory),
-                           reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status, nullptr, nullptr, nullptr, 0);
+                           reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status, nullptr, nullptr, nullptr, 0, cycles);
     else
         hipLaunchKernelGGL(stream_scan_kernel<0>, grid, dim3(THREADS - 64), LDS_BYTES, s, nullptr, reinterpret_cast<const float2 *>(x), mixer,
                            reinterpret_cast<float2 *>(memory), reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status,
-                           nullptr, nullptr, nullptr, 0);
+                           nullptr, nullptr, nullptr, 0, cycles);
     return (int)hipGetLastError();
 }
 

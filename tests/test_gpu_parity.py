@@ -1474,3 +1474,42 @@ def test_streams_leave_the_shared_carrier(oracle):
                 assert cpu(o["index"])[s_] == om[s_].index, (round_, k, s_)
                 assert bits_equal(cpu(o["sym"][s_]), om[s_].symbols) and bits_equal(cpu(o["costas"][s_]), om[s_].costas_frame), (round_, k, s_)
                 assert cpu(o["phase"])[s_] == om[s_].phase and cpu(o["freq"])[s_] == om[s_].freq, (round_, k, s_)
+
+
+@pytest.mark.parametrize("kind", ["pcm", "pcm_own_carrier", "cplx"])
+@pytest.mark.parametrize("fixed", [None, 2, 6])
+@pytest.mark.parametrize("L,S", [(256, 20), (1024, 33)])
+def test_stream_scan_kernel_at_four_samples_per_symbol(oracle, L, S, fixed, kind):
+    """stream_scan_kernel at CYCLES = 4, the reference's shipped rates (FS 9600 / RS 2400): a lane's 8 outputs are two symbols, the
+    filtered block has four planes, the histogram keeps its 8 bins -- so the timing index (and a fixed one: 6) may be CYCLES or more
+    and the pick reaches into the next symbol, past the block for the last one (0.0) -- block after block against the
+    oracle's modems, PCM (the streams' one carrier / every stream's own) and complex input"""
+    fs, rs = 9600.0, 2400.0
+    kw = dict(timing_mode=TIMING_FIXED, fixed_index=fixed) if fixed is not None else {}
+    m = modem(fs=fs, rs=rs, frame_size=L, **kw)
+    m.tune(stream_block=0)
+    m.tune(stream_scan=1)
+    m.tune(stream_carrier=0 if kind == "pcm_own_carrier" else 1)
+    m.streams_reset(S, 1500.0)
+    om = [oracle.modem(fs, rs, L, loop_bw=BW, **kw) for _ in range(S)]
+    for o in om:
+        o.set_mixer_hz(1500.0)
+    rng = np.random.default_rng(L + S + (fixed or 0))
+    for k in range(5):
+        if kind == "cplx":
+            blk = rng.standard_normal((S, L, 2)).astype(np.float32)
+            if k == 2:
+                blk[1] = 0.0
+            o = m.streams_rx_cplx(blk)
+        else:
+            blk = (6000 * rng.standard_normal((S, L))).astype(np.int16)
+            if k == 2:
+                blk[1] = 0
+            o = m.streams_rx_pcm(blk)
+        m.sync()
+        assert m.last_kernel() == "stream_scan_kernel + costas_pipe_kernel"
+        for s_ in range(S):
+            (om[s_].rx_cplx if kind == "cplx" else om[s_].rx_pcm)(blk[s_])
+            assert cpu(o["index"])[s_] == om[s_].index, (k, s_)
+            assert bits_equal(cpu(o["sym"][s_]), om[s_].symbols) and bits_equal(cpu(o["costas"][s_]), om[s_].costas_frame), (k, s_)
+            assert cpu(o["phase"])[s_] == om[s_].phase and cpu(o["freq"])[s_] == om[s_].freq, (k, s_)
