@@ -1028,7 +1028,11 @@ static bool stream_block_ok(const qpsk_ctx *c, bool pcm)
     /* [measured, profiles/r04_streams_short_blocks.txt: PCM streams back to back] the kernels apart cost 70 us (512-sample blocks) to
      * 220 us (2048) whatever the count -- launches and serial chains -- and this kernel ~17 us + 13.5 ns per 512 samples of a stream:
      * it wins up to ~4 M samples per block of all streams (7800 x 512, 4400 x 1024, 2400 x 2048).  Complex input: round 4's first rule */
-    return t == 1 || (pcm ? (long long)c->nstreams * c->prm.frame_size <= 3500000LL : c->nstreams <= 1024);
+    const long long nl = (long long)c->nstreams * c->prm.frame_size;
+    /* complex input has no carrier chain in front of it: at CYCLES = 8 the kernels apart (hand-scheduled filter, 8-lane scan) take 29 us
+     * at 1024 x 512 and 55 us at 256 x 2048, where this kernel takes 27 and 73 -- it keeps the small batches (<= 0.4 M samples); at other
+     * rates the kernels apart run the generic scan (72 us at 2048 x 512 against 40 here) and the PCM rule holds */
+    return t == 1 || (pcm || c->cycles != 8 ? nl <= 3500000LL : nl <= 400000LL);
 }
 
 /* PCM streams that both stream_scan_kernel and the one-launch kernel would take: which of the two */
@@ -1190,11 +1194,12 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
     if (!c || !d_in) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_cplx: null argument");
     if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
     if (bind(c)) return QPSK_ERR_HIP;
-    if (d_sym && stream_block_ok(c, false)) {
+    const bool scan = stream_scan_ok(c, false, false) && ((uintptr_t)d_in % 16) == 0;
+    if (d_sym && stream_block_ok(c, false) && !prefer_stream_scan(c, scan)) {
         if (int rb = streams_block_launch(c, nullptr, d_in, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
         return streams_copy_loop(c, d_freq, d_phase);
     }
-    if (stream_scan_ok(c, false, false) && ((uintptr_t)d_in % 16) == 0)
+    if (scan)
         return streams_scanned(c, nullptr, d_in, d_sym, d_freq, d_phase, d_costas, d_index);
     return streams_from_filter(c, d_in, false, d_sym, d_freq, d_phase, d_costas, d_index);
 }

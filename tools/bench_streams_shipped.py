@@ -15,10 +15,12 @@ import qpsk_amd  # noqa: E402
 dev = torch.device("cuda", 0)
 L = int(os.environ.get("QPSK_BENCH_L", "512"))
 FS = float(os.environ.get("QPSK_BENCH_FS", "9600"))
+CPLX = os.environ.get("QPSK_BENCH_CPLX", "0") == "1"      # complex blocks at the rrc_fir() call (qpsk_streams_rx_cplx) instead of PCM
 for n in [int(a) for a in sys.argv[1:]] or [256, 1024, 2048, 4096, 16384]:
     g = torch.Generator(device=dev)
     g.manual_seed(n)
     pcm = (6000 * torch.randn((n, L), generator=g, device=dev)).to(torch.int16)
+    xc = torch.randn((n, L, 2), generator=g, device=dev, dtype=torch.float32) if CPLX else None
     res = []
     for block, scan in ((1, 0), (0, 0)) + (((0, 1),) if L % 256 == 0 else ()) + ((None, None),):      # last: the library's own choice
         m = qpsk_amd.Modem(fs=FS, rs=2400.0, frame_size=L, timing_mode=qpsk_amd.TIMING_HIST)
@@ -29,7 +31,10 @@ for n in [int(a) for a in sys.argv[1:]] or [256, 1024, 2048, 4096, 16384]:
         fr = torch.empty((n,), dtype=torch.float32, device=dev)
         ph = torch.empty_like(fr)
         idx = torch.empty((n,), dtype=torch.int32, device=dev)
-        fn = lambda: m._check(m.L.qpsk_streams_rx_pcm(m.h, pcm.data_ptr(), sym.data_ptr(), fr.data_ptr(), ph.data_ptr(), None, idx.data_ptr()))
+        if CPLX:
+            fn = lambda: m._check(m.L.qpsk_streams_rx_cplx(m.h, xc.data_ptr(), sym.data_ptr(), fr.data_ptr(), ph.data_ptr(), None, idx.data_ptr()))
+        else:
+            fn = lambda: m._check(m.L.qpsk_streams_rx_pcm(m.h, pcm.data_ptr(), sym.data_ptr(), fr.data_ptr(), ph.data_ptr(), None, idx.data_ptr()))
         for _ in range(20):
             fn()
         torch.cuda.synchronize()
@@ -45,4 +50,4 @@ for n in [int(a) for a in sys.argv[1:]] or [256, 1024, 2048, 4096, 16384]:
             last = e0.elapsed_time(e1) / 200
         res.append((("the library's choice: " if block is None else "") + m.last_kernel(), last))
         m.close()
-    print("%6d streams x %d samples at FS %g: " % (n, L, FS) + "; ".join("%s %.1f us per block (%.0f Msamples/s)" % (k, t * 1e3, n * L / t / 1e3) for k, t in res), flush=True)
+    print("%6d streams x %d samples at FS %g%s: " % (n, L, FS, ", complex input" if CPLX else "") + "; ".join("%s %.1f us per block (%.0f Msamples/s)" % (k, t * 1e3, n * L / t / 1e3) for k, t in res), flush=True)
