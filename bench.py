@@ -551,6 +551,22 @@ def main():
             st["stream0_block2_index_ok"] = bool(int(o_last["index"]) == int(om.index))
             st["stream0_block2_loop_bits_ok"] = bool(np.float32(o_last["phase"]) == np.float32(om.phase) and np.float32(o_last["freq"]) == np.float32(om.freq))
         ms_.close(); mtx.close()
+        # the same block size at the reference's SHIPPED rates (FS 9600 / RS 2400, CYCLES 4: qpsk.h:16-23): twice the symbols per block
+        ms4 = qpsk_amd.Modem(fs=9600.0, rs=2400.0, frame_size=L, timing_mode=qpsk_amd.TIMING_HIST, device=local)
+        ms4.streams_reset(S_, 1500.0)
+        pcm4 = (6000 * torch.randn((S_, L), generator=gen, device=dev)).to(torch.int16)
+        t4 = []
+        for k in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ms4.streams_rx_pcm(pcm4, want_costas=False)
+            e1.record()
+            torch.cuda.synchronize()
+            t4.append(e0.elapsed_time(e1))
+        ms4.sync()
+        st["shipped_rates_pcm_block_ms"] = float(np.median(t4[2:]))
+        st["shipped_rates_kernels"] = ms4.last_kernel()
+        ms4.close()
         m1 = qpsk_amd.Modem(fs=9600.0, rs=2400.0, frame_size=512, device=local)
         m1.streams_reset(1, 1500.0)
         rng = np.random.default_rng(1)
