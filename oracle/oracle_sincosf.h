@@ -13,17 +13,20 @@
  * sine / degree-8 cosine polynomials, result narrowed to float).
  *
  * Pin: tools/check_sincosf.c compares these functions with the container's
- * libm sinf/cosf over EVERY float in [-120, 120] (the whole reduce_fast
- * domain; the Costas phase only reaches [-2pi, 2pi]) and must report zero
- * mismatches.  x86-64 glibc selects an FMA build of the same C source at run
- * time; ORACLE_SC_FMA=1 restates that build (contracted a*b+c), 0 the plain
- * one.  The checker decides which one libm here is.
+ * libm sinf/cosf over EVERY float bit pattern -- all finite arguments of both
+ * signs (the fast reduction below 120, the large-argument reduction above),
+ * the infinities and the NaNs -- and must report zero mismatches.  x86-64
+ * glibc selects an FMA build of the same C source at run time;
+ * ORACLE_SC_FMA=1 restates that build (contracted a*b+c), 0 the plain one.
+ * The checker decides which one libm here is.
  *
- * Only |x| < 120 is restated (the slow Payne-Hanek path of the library for
- * larger arguments is unreachable on the QPSK receive path: the phase is
- * wrapped to [-2pi, 2pi] (costas_loop.c:61-67) and rrc_make arguments stay
- * below 1.35*pi*63/spb).  Out-of-domain arguments return NaN so that a misuse
- * is loud.
+ * Both of the library's reductions are restated.  The Costas phase only
+ * reaches [-2pi, 2pi] (costas_loop.c:61-67), but rrc_make() does reach the
+ * large-argument one: its arguments go up to (1+alpha)*pi*63*RS/FS
+ * (rrc_fir.c:46-49,62-64), which passes 120 from FS/RS <= 2.2 at alpha = .35
+ * (round 4's restatement stopped at 120 and answered NaN there; the
+ * reference's taps are finite).  Infinities and NaNs give NaN, as the
+ * library's __math_invalidf does (the sign of that NaN is not pinned).
  */
 #ifndef ORACLE_SINCOSF_H
 #define ORACLE_SINCOSF_H
@@ -80,6 +83,44 @@ static inline double osc_cos_poly(double x2)
     return OSC_MADD(x6, c2, c);
 }
 
+/*
+ * The library's reduce_large(): |y| >= 120.  The mantissa of y (24 bits, shifted left by the low three bits of the
+ * exponent) times a 96-bit window of 2/pi, picked by the exponent's upper bits from a table of 32-bit words that slide
+ * one BYTE at a time over the bits of 2/pi; the 64-bit fixed-point product counts quarter turns in units of 2^-62: its top
+ * two bits, rounded to nearest, are the quadrant, and what is left, a signed number in [-2^61, 2^61], times
+ * (pi/2) * 2^-62 is the reduced argument in [-pi/4, pi/4].  The sign of y is ignored here; the callers fold it into the
+ * quadrant.
+ */
+static const uint32_t osc_inv_pio4[24] = {
+    /* the library calls it __inv_pio4; 2/pi = 0.a2f9836e 4e441529 fc2757d1 f534ddc0 db629599 3c439041 (hex) read through
+     * a 32-bit window at byte offsets -3, -2, ... 20 (tests/test_sincos.py recomputes the digits with integer arithmetic) */
+    0x000000a2, 0x0000a2f9, 0x00a2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+    0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+    0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041,
+};
+#define OSC_PI63 0x1.921FB54442D18p-62 /* (pi/2) * 2^-62: the library's pi63 = 2 pi / 2^64 */
+
+static inline double osc_reduce_large(uint32_t xi, int *np)
+{
+    const uint32_t *arr = &osc_inv_pio4[(xi >> 26) & 15];
+    const int shift = (xi >> 23) & 7;
+    uint64_t n, res0, res1, res2;
+
+    xi = (xi & 0xffffff) | 0x800000;
+    xi <<= shift;
+
+    res0 = (uint32_t)(xi * arr[0]); /* 32-bit product: the bits above are whole turns */
+    res1 = (uint64_t)xi * arr[4];
+    res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+
+    n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int)n;
+    return (double)(int64_t)res0 * OSC_PI63;
+}
+
 /* both results for one argument; *sn = sinf(y), *cs = cosf(y) */
 static inline void oracle_sincosf(float y, float *sn, float *cs)
 {
@@ -118,7 +159,39 @@ static inline void oracle_sincosf(float y, float *sn, float *cs)
         }
         return;
     }
-    *sn = NAN;
+    if (osc_abstop12(y) < osc_abstop12(INFINITY)) {
+        /* s_sinf.c / s_cosf.c, last finite branch.  sinf: the sign bit of y is ADDED to the quadrant that picks the result's
+         * sign and the negated table (sin is odd), not to the one that picks sine or cosine polynomial */
+        const uint32_t xi = osc_asuint(y);
+        const int sign = (int)(xi >> 31);
+        int n;
+        const double xr = osc_reduce_large(xi, &n);
+        const int ns = n + sign;
+        /* sinf: sign[(n + sign) & 3], the negated table if (n + sign) & 2 */
+        {
+            const double sg = ((ns & 3) == 1 || (ns & 3) == 2) ? -1.0 : 1.0;
+            const double x2 = xr * xr;
+            double r;
+            if (n & 1)
+                r = (ns & 2) ? -osc_cos_poly(x2) : osc_cos_poly(x2);
+            else
+                r = osc_sin_poly(xr * sg, x2);
+            *sn = (float)r;
+        }
+        /* cosf: sign[n & 3], the negated table if n & 2 (cos is even: the sign of y plays no part), polynomial by n ^ 1 */
+        {
+            const double sg = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+            const double x2 = xr * xr;
+            double r;
+            if ((n ^ 1) & 1)
+                r = (n & 2) ? -osc_cos_poly(x2) : osc_cos_poly(x2);
+            else
+                r = osc_sin_poly(xr * sg, x2);
+            *cs = (float)r;
+        }
+        return;
+    }
+    *sn = NAN; /* inf, NaN: __math_invalidf */
     *cs = NAN;
 }
 

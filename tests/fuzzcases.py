@@ -13,7 +13,8 @@ from oracle.pyoracle import TAU, TIMING_FFT, TIMING_FIXED, TIMING_HIST
 from sigutil import bits_equal, make_frames
 
 RATES = [(9600.0, 2400.0), (19200.0, 2400.0), (19200.0, 2400.0), (19200.0, 2400.0), (9600.0, 1200.0), (12000.0, 2400.0),
-         (20000.0, 2400.0), (38400.0, 2400.0), (7200.0, 2400.0), (14400.0, 2400.0)]
+         (20000.0, 2400.0), (38400.0, 2400.0), (7200.0, 2400.0), (14400.0, 2400.0),
+         (4800.0, 2400.0)]   # two samples per symbol: rrc_make()'s cosf/sinf arguments pass 120 (glibc's large-argument reduction)
 
 
 def _pick(rng, seq):
@@ -63,14 +64,15 @@ def batch_case(oracle, modem_factory, seed, max_samples=6_000_000):
     cycles = int(fs / rs)
     alpha = float(np.float32(rng.uniform(0.2, 0.6))) if rng.integers(0, 3) == 0 else 0.35
     taps = oracle.rrc_make(fs, rs, np.float32(alpha))
-    if not np.all(np.isfinite(taps)):
-        return "seed %d: rrc_make(%g, %g, %g) is not finite, skipped" % (seed, fs, rs, alpha), None
+    # the reference's rrc_make() is finite at every rate and roll-off drawn here (tests/test_oracle_vs_ref.py's grid); an oracle that
+    # says otherwise is a broken checker, not a case to skip (round 4 skipped, and hid the oracle's hole above |x| = 120)
+    assert np.all(np.isfinite(taps)), "oracle rrc_make(%g, %g, %g) is not finite" % (fs, rs, alpha)
     nsym = int(_pick(rng, [128, 128, 192, 256, 100, 37])) if big else _nsym(rng)
     L = nsym * cycles
     F = int(rng.integers(4097, 9000)) if big else int(_pick(rng, [rng.integers(1, 6), rng.integers(6, 80), rng.integers(80, 700)]))
     F = max(1, min(F, (2 * max_samples if big else max_samples) // L))
     mode = int(_pick(rng, [TIMING_FIXED, TIMING_FIXED, TIMING_HIST, TIMING_HIST, TIMING_FFT]))
-    if mode == TIMING_FFT and (L < 128 + 512 + 126 or cycles not in (4, 8)):      # the library's FFT estimate: CYCLES 2, 4, 8
+    if mode == TIMING_FFT and (L < 128 + 512 + 126 or cycles not in (2, 4, 8)):   # the library's FFT estimate: CYCLES 2, 4, 8
         mode = TIMING_HIST
     fixed = int(rng.integers(0, min(cycles, 8)))                                    # the reference's histograms have 8 bins (qpsk.c:130)
     bw = np.float32(TAU / 100.0) if rng.integers(0, 2) else np.float32(TAU / 100.0 * 10.0 ** rng.uniform(-1, 0.7))
@@ -118,8 +120,7 @@ def streams_case(oracle, modem_factory, seed):
     fs, rs = _pick(rng, RATES)
     cycles = int(fs / rs)
     taps = oracle.rrc_make(fs, rs, np.float32(0.35))
-    if not np.all(np.isfinite(taps)):
-        return "seed %d: taps not finite, skipped" % seed, None
+    assert np.all(np.isfinite(taps)), "oracle rrc_make(%g, %g, .35) is not finite" % (fs, rs)
     nsym = _nsym(rng)
     many = rng.integers(0, 6) == 0      # thousands of streams, whole 256-sample tiles at CYCLES = 8, histogram timing: stream_scan_kernel
     if many:
@@ -135,7 +136,7 @@ def streams_case(oracle, modem_factory, seed):
     mode = int(_pick(rng, [TIMING_HIST, TIMING_HIST, TIMING_FIXED, TIMING_FFT]))
     if many:
         mode = TIMING_HIST
-    if mode == TIMING_FFT and (L < 128 + 512 + 126 or cycles not in (4, 8)):
+    if mode == TIMING_FFT and (L < 128 + 512 + 126 or cycles not in (2, 4, 8)):
         mode = TIMING_HIST
     fixed = int(rng.integers(0, min(cycles, 8)))
     bw = np.float32(TAU / 100.0)
@@ -192,8 +193,7 @@ def stages_case(oracle, modem_factory, seed):
     fs, rs = _pick(rng, RATES)
     cycles = int(fs / rs)
     taps = oracle.rrc_make(fs, rs, np.float32(0.35))
-    if not np.all(np.isfinite(taps)):
-        return "seed %d: taps not finite, skipped" % seed, None
+    assert np.all(np.isfinite(taps)), "oracle rrc_make(%g, %g, .35) is not finite" % (fs, rs)
     what = _pick(rng, ["fir", "fir", "hist", "costas", "fft", "tx", "bits"])
     m = modem_factory(fs=fs, rs=rs, frame_size=cycles * 64, loop_bw=np.float32(TAU / 100.0))
     desc = "seed %d: fs %g rs %g stage %s" % (seed, fs, rs, what)

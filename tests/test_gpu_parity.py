@@ -100,7 +100,8 @@ def test_rx_batch_reference_timing(oracle, fs, rs, L, F):
     assert_batch_equal(got, want)
 
 
-@pytest.mark.parametrize("fs,rs,L,F", [(19200.0, 2400.0, 1024, 40), (19200.0, 2400.0, 16384, 6), (9600.0, 2400.0, 2048, 33)])
+@pytest.mark.parametrize("fs,rs,L,F", [(19200.0, 2400.0, 1024, 40), (19200.0, 2400.0, 16384, 6), (9600.0, 2400.0, 2048, 33),
+                                       (4800.0, 2400.0, 1024, 21)])
 def test_rx_batch_fft_timing(oracle, fs, rs, L, F):
     """config 3: the FFT timing estimate (new design on top of the reference's radix-2 FFT) in front of the
     fused kernel -- parity with the oracle's restatement of the same definition (unpinned by the reference)"""

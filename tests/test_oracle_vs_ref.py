@@ -11,6 +11,39 @@ pytestmark = pytest.mark.skipif(not ref_available("c1small"), reason="oracle/_re
 BW = np.float32(TAU / 100.0)
 
 
+def rrc_grid():
+    """(fs, rs, alpha) sets for rrc_make(): samples per symbol from 1 up, roll-offs to 1.  Below FS/RS ~ 2.2 (alpha .35) the
+    arguments of cosf/sinf (rrc_fir.c:46-49,62-64) pass 120 and glibc takes its large-argument reduction."""
+    out = []
+    for rs in (2400.0, 1200.0, 300.0):
+        for spb in (1.0, 5.0 / 3.0, 2.0, 2.2, 2.5, 3.0, 10.0 / 3.0, 4.0, 5.0, 8.0, 16.0, 20.0, 160.0):
+            for alpha in (.05, .1, .2, .25, .35, .5, .6, .75, .8, .9, 1.0):
+                out.append((np.float32(rs * spb), np.float32(rs), np.float32(alpha)))
+    return out
+
+
+def test_rrc_make_matches_reference(oracle):
+    """rrc_make() (rrc_fir.c:32-76): oracle == reference == the product's host routine, bit for bit, on every set -- round 4's
+    oracle answered NaN taps where the reference's cosf/sinf arguments reach 120 (FS/RS <= 2.2 at alpha .35)."""
+    import ctypes as C
+    import qpsk_amd
+    hip = C.CDLL(qpsk_amd.lib_path())          # host symbol only: no GPU call
+    hip.qpsk_host_rrc_taps.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    hip.qpsk_host_rrc_taps.restype = None
+    ref = Reference("shipped")
+    large = 0
+    for fs, rs, alpha in rrc_grid():
+        want = ref.taps(fs, rs, alpha)
+        got = oracle.rrc_make(fs, rs, alpha)
+        prod = np.zeros(127, np.float32)
+        hip.qpsk_host_rrc_taps(fs, rs, alpha, prod.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.isfinite(want).all(), (fs, rs, alpha)   # the reference's taps are finite on the whole grid
+        assert bits_equal(got, want), ("oracle", fs, rs, alpha)
+        assert bits_equal(prod, want), ("product", fs, rs, alpha)
+        large += (1.0 + float(alpha)) * np.pi * 63.0 * float(rs) / float(fs) >= 120.0
+    assert large >= 40          # the grid does reach the large-argument path
+
+
 @pytest.mark.parametrize("name", ["shipped", "c1small", "c5small"])
 def test_streaming_pcm_matches_reference(oracle, name):
     ref = Reference(name)

@@ -1,9 +1,10 @@
 """sinf/cosf: the oracle's restatement (oracle/oracle_sincosf.h) and the routine the GPU kernels run
 (qpsk_amd/csrc/sincos_f32.h, compiled here for the host) against this machine's libm, which is where
-the reference gets its values (qpsk.h:35-36).  The exhaustive sweeps are tools/check_sincosf.c and
-tools/check_device_sincos.cpp (every float in [-120, 120]: 0 mismatches); this test
-runs the same programs over the Costas domain [-2pi, 2pi] boundaries and a dense random sample so that
-the CPU suite stays short."""
+the reference gets its values (qpsk.h:35-36).  The exhaustive sweeps are tools/check_sincosf.c (EVERY float
+bit pattern: 0 mismatches, 11 s on 8 cores) and tools/check_device_sincos.cpp (every float in [-120, 120],
+see DESIGN.md); this test runs the oracle's checker over the whole large-argument domain [120, inf] -- the
+part rrc_make() reaches at low samples per symbol (rrc_fir.c:46-49,62-64) and round 4's oracle lacked --
+and both programs over the smallest arguments and a dense random sample so that the CPU suite stays short."""
 import os
 import subprocess
 import sys
@@ -25,6 +26,39 @@ def test_oracle_sincosf_equals_libm_small_range(tmp_path):
     # bit patterns up to 2^-6 are ~1.0e9) -> keep to |x| <= 2^-100 here plus the sampled test below
     r = _run("check_sincosf.c", ["-DORACLE_SC_FMA=1"], str(tmp_path / "chk"), ["1e-30"])
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_oracle_sincosf_equals_libm_every_large_argument(tmp_path):
+    """glibc's reduce_large path, |x| >= 120 up to and including the infinities: 2 x 1,016,070,145 arguments"""
+    r = _run("check_sincosf.c", ["-DORACLE_SC_FMA=1"], str(tmp_path / "chk"), ["120", "inf"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "checked=2032140290 " in r.stdout, r.stdout
+
+
+def test_two_over_pi_table_digits():
+    """the 24 words of oracle_sincosf.h's osc_inv_pio4[] are 2/pi's bits through a 32-bit window sliding a byte at a time;
+    2/pi recomputed here with integer arithmetic (Machin's formula)"""
+    import re
+
+    def atan_inv(x, bits):
+        total, term, n, sign = 0, (1 << bits) // x, 1, 1
+        while term:
+            total += sign * (term // n)
+            term //= x * x
+            n += 2
+            sign = -sign
+        return total
+
+    B = 400
+    pi = 4 * (4 * atan_inv(5, B) - atan_inv(239, B))
+    frac = ((2 << (2 * B)) // pi) >> (B - 192)          # the first 192 bits of 2/pi
+    want = [(frac >> (192 - 8 * (k + 1))) & 0xffffffff for k in range(24)]      # word k = floor(2/pi * 2^(8 (k + 1))) mod 2^32
+    src = open(os.path.join(ROOT, "oracle", "oracle_sincosf.h")).read()
+    body = src[src.index("osc_inv_pio4[24] = {"):]
+    body = body[:body.index("};")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    got = [int(w, 16) for w in re.findall(r"0x[0-9a-fA-F]{8}", body)]
+    assert got == want
 
 
 def test_device_form_equals_libm_small_range(tmp_path):

@@ -1,13 +1,17 @@
 /*
  * check_sincosf.c -- pins oracle/oracle_sincosf.h against the C library the
- * reference links (glibc libm sinf/cosf, reference qpsk.h:35-36).
+ * reference links (glibc libm sinf/cosf, reference qpsk.h:35-36; rrc_fir.c:46-49,62-64
+ * reaches the large-argument reduction, costas_loop.c / qpsk.c only [-2pi, 2pi]).
  *
- * Walks every float bit pattern with |x| <= LIMIT (default 120.0f = the whole
- * fast-reduction domain of the library routine) in both signs and counts the
- * arguments where the restatement and libm differ in any bit.
+ * Walks every float bit pattern with LO <= |x| <= HI in both signs and counts the
+ * arguments where the restatement and libm differ in any bit.  Defaults: LO = 0,
+ * HI = +inf, i.e. EVERY finite float and both infinities (2 x 2,139,095,041 arguments:
+ * about two minutes on 8 cores); for infinities and NaNs only NaN-ness is compared.
  *
  *   gcc -O2 -ffp-contract=off -fopenmp -DORACLE_SC_FMA=1 tools/check_sincosf.c -o /tmp/chk -lm
- *   /tmp/chk [limit]
+ *   /tmp/chk            # everything
+ *   /tmp/chk HI         # |x| <= HI
+ *   /tmp/chk LO HI      # LO <= |x| <= HI   ("inf" is accepted)
  *
  * Exit status 0 iff zero mismatches.
  */
@@ -15,39 +19,50 @@
 #include <stdlib.h>
 #include "../oracle/oracle_sincosf.h"
 
+static int same(float a, float b)
+{
+    if (isnan(a) || isnan(b))
+        return isnan(a) && isnan(b);
+    return osc_asuint(a) == osc_asuint(b);
+}
+
 int main(int argc, char **argv)
 {
-    float limit = argc > 1 ? (float)atof(argv[1]) : 120.0f;
-    uint32_t top = osc_asuint(limit);
-    if (osc_abstop12(limit) >= osc_abstop12(120.0f))
-        top = osc_asuint(120.0f) - 1; /* largest float strictly inside the domain test */
+    float lo = 0.f, hi = INFINITY;
+    if (argc == 2)
+        hi = strtof(argv[1], NULL);
+    else if (argc > 2) {
+        lo = strtof(argv[1], NULL);
+        hi = strtof(argv[2], NULL);
+    }
+    const uint32_t first = osc_asuint(fabsf(lo)), top = osc_asuint(fabsf(hi));
     unsigned long long bad_s = 0, bad_c = 0, n = 0;
     uint32_t first_bad = 0;
     int have_first = 0;
 #pragma omp parallel for schedule(static, 1 << 16) reduction(+ : bad_s, bad_c, n)
-    for (uint32_t b = 0; b <= top; b++) {
+    for (uint64_t b = first; b <= top; b++) {
         for (int sg = 0; sg < 2; sg++) {
-            uint32_t u = b | ((uint32_t)sg << 31);
+            uint32_t u = (uint32_t)b | ((uint32_t)sg << 31);
             float y;
             memcpy(&y, &u, 4);
             float s, c;
             oracle_sincosf(y, &s, &c);
             float ls = sinf(y), lc = cosf(y);
             n++;
-            if (osc_asuint(s) != osc_asuint(ls)) {
+            if (!same(s, ls)) {
                 bad_s++;
 #pragma omp critical
                 if (!have_first) { have_first = 1; first_bad = u; }
             }
-            if (osc_asuint(c) != osc_asuint(lc)) {
+            if (!same(c, lc)) {
                 bad_c++;
 #pragma omp critical
                 if (!have_first) { have_first = 1; first_bad = u; }
             }
         }
     }
-    printf("variant ORACLE_SC_FMA=%d limit=%a checked=%llu sin_mismatch=%llu cos_mismatch=%llu\n",
-           ORACLE_SC_FMA, limit, n, bad_s, bad_c);
+    printf("variant ORACLE_SC_FMA=%d lo=%a hi=%a checked=%llu sin_mismatch=%llu cos_mismatch=%llu\n",
+           ORACLE_SC_FMA, lo, hi, n, bad_s, bad_c);
     if (have_first) {
         float y;
         memcpy(&y, &first_bad, 4);

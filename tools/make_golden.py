@@ -53,7 +53,10 @@ def tx_complex(ref, rng, nblocks, offset_hz):
 def gen_taps():
     ref = Reference("shipped")
     cases = [(9600, 2400, .35), (19200, 2400, .35), (9600, 1200, .35), (19200, 2400, .5), (19200, 2400, .25),
-             (9600, 2400, .5), (9600, 1200, 1.0), (48000, 300, .2), (8000, 2400, .35)]
+             (9600, 2400, .5), (9600, 1200, 1.0), (48000, 300, .2), (8000, 2400, .35),
+             # low samples per symbol: (1 + alpha) pi 63 RS/FS >= 120, glibc's large-argument cosf/sinf (rrc_fir.c:46-49,62-64)
+             (4800, 2400, .35), (4800, 2400, 1.0), (4000, 2400, .35), (2400, 2400, .35), (2400, 2400, .9), (5280, 2400, .35),
+             (7200, 2400, .9)]
     arr = np.stack([ref.taps(np.float32(a), np.float32(b), np.float32(c)) for a, b, c in cases])
     np.savez(os.path.join(OUT, "taps.npz"), cases=np.array(cases, np.float64), taps=arr)
 
