@@ -279,7 +279,8 @@ def main():
 
     def timed_region(m_, x_, F, outs, steps, warmup, settle):
         """W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides.  Returns (wall
-        seconds of the K steps on this rank, kernel ms per launch from HIP events on the launch stream)."""
+        seconds of the K steps on this rank: from leaving the leading barrier + synchronize to the return of the
+        synchronize behind the last step; kernel ms per launch from HIP events on the launch stream)."""
         sym_, freq_, phase_ = outs
         # clock settle, before the W warmup steps and outside every count: a step is 0.2-0.3 ms, so W + K = 25 steps
         # are over in 5 ms, before the GPU has left its idle clocks (DESIGN.md 6)
@@ -302,8 +303,12 @@ def main():
             m_.rx_batch_raw(x_, F, sym_, freq_, phase_)
         ev1.record()
         torch.cuda.synchronize()
-        barrier()
+        # this rank's clock stops HERE, when its K steps are done; the job's time is the MAX over ranks of these (the slowest
+        # rank defines the job).  The trailing barrier still brackets the region, but it is not timed: a gloo rendezvous costs
+        # 0.4-0.8 ms (profiles/r04_bench_gpus2_shared.json: 0.76 ms per region), i.e. 13 % of a 20-step region of 0.26 ms steps --
+        # a tax the N = 1 line (no barrier) does not pay, which would have made a perfect 8x read 6.9x.
         dt = time.perf_counter() - t0
+        barrier()
         m_.sync()      # raises if a kernel's in-LDS pipeline gave up (bounded spins): such a run has no valid timing
         return dt, ev0.elapsed_time(ev1) / steps
 
@@ -384,6 +389,7 @@ def main():
         "value": value, "unit": "Msamples/s", "n_gpus": ndistinct, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "clock_settle_s": args.settle,
+        "clock": "per rank: barrier + synchronize, K launches, synchronize -> stop; MAX over ranks; the trailing barrier is outside the clock",
         "stimulus": ("library transmit chain: random dibits -> qpsk_tx_symbols (tx_shape_kernel: Gray map, zero-stuffing, TX RRC) -> +50 Hz rotation"
                      if args.stimulus == "tx" else "torch: random dibits -> Gray map -> zero-stuffing -> conv1d with the RX taps -> +50 Hz rotation"),
         # n_gpus counts DISTINCT physical devices (host + PCI address of every rank, gathered); ranks that share a GPU

@@ -116,6 +116,23 @@ def test_bench_gpus_2_starts_two_ranks():
     assert d["control_plane"].startswith("gloo")
 
 
+@pytest.mark.gpu
+def test_two_rank_clock_excludes_the_rendezvous():
+    """The N > 1 clock stops when a rank's K steps are done, in front of the trailing barrier (round 4 timed the gloo rendezvous:
+    0.76 ms per region = 13 % of the driver's 20-step region).  Two ranks at the real per-GPU shape (8192 x 16384 each, sharing the
+    one GPU of this box), --steps 20 like the driver: the job's wall time per step must be the kernels' time -- rank 0's event span
+    over its K launches, which on a shared GPU contains the other rank's launches too -- within 2 %."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["ranks"] == 2 and d["steps"] == 20 and d["config"]["frames_per_gpu"] == 8192
+    assert d["parity"]["symbol_mismatches"] == 0 and d["parity"]["hz_out_of_range"] == 0
+    wall, kern = d["ms_per_step"], d["roofline"]["kernel_ms"]
+    assert abs(wall - kern) < 0.02 * kern, (wall, kern)
+
+
 def test_bench_gpus_flag_is_not_ignored():
     """CPU side of the same contract: without a GPU `--gpus 2` still starts two ranks (both fail loudly: no CPU path)
     and the parent exits non-zero; a --gpus that contradicts WORLD_SIZE is refused."""
