@@ -9,8 +9,22 @@
  * reference's.  Each prototype cites the declaration it replaces
  * (file:line in the reference tree).
  *
- * C only: the by-value "complex float" parameters are C99 types
- * (the reference headers pull in <complex.h> the same way).
+ * C and C++: the reference's headers carry extern "C" guards (rrc_fir.h:7-9,
+ * costas_loop.h:9-12, fft.h:32-35); so does this one.  In C the complex types
+ * are <complex.h>'s, as in the reference.  A C++ translation unit gets the
+ * pointer-taking functions with the compiler's _Complex types (an extension
+ * both g++ and hipcc/clang++ accept; same layout, float[2] / double[2]); the
+ * two functions that take a complex float BY VALUE -- phase_detector(),
+ * qpsk_demod() -- are declared for C only.
+ *
+ * The names the reference's caller takes from those headers are here too:
+ * NTAPS, GAIN (rrc_fir.h:13-14: qpsk.c:36-37 sizes tx_filter[NTAPS] /
+ * rx_filter[NTAPS] with them) and NFFT (fft.h:44).
+ *
+ * qpsk.c keeps rx_frame() and qpsk_demod() file-static (qpsk.c:24-25).  A
+ * caller that keeps those definitions and wants only the primitives from the
+ * GPU defines QPSK_DROPIN_PRIMITIVES_ONLY before the include: the two names
+ * are then not declared here (patch A).
  *
  * What the reference fixed with #defines (FS, RS, CENTER, FRAME_SIZE,
  * qpsk.h:16-23) is set once with qpsk_dropin_configure(); without that call
@@ -23,13 +37,29 @@
 #ifndef QPSK_DROPIN_H
 #define QPSK_DROPIN_H
 
-#ifdef __cplusplus
-#error "qpsk_dropin.h is a C header (C99 complex by-value parameters); C++ callers use qpsk_hip.h"
-#endif
-
-#include <complex.h>
 #include <stdint.h>
 #include "qpsk_hip.h"
+
+#ifdef __cplusplus
+typedef float _Complex qpsk_dropin_cfloat;
+typedef double _Complex qpsk_dropin_cdouble;
+extern "C" {
+#else
+#include <complex.h>
+typedef complex float qpsk_dropin_cfloat;
+typedef complex double qpsk_dropin_cdouble;
+#endif
+
+/* ---- the constants of rrc_fir.h and fft.h ------------------------------ */
+#ifndef NTAPS
+#define NTAPS 127                                                          /* rrc_fir.h:13 */
+#endif
+#ifndef GAIN
+#define GAIN 1.85                                                          /* rrc_fir.h:14 */
+#endif
+#ifndef NFFT
+#define NFFT 512                                                           /* fft.h:44 */
+#endif
 
 /* ---- configuration that the reference hard-codes ---------------------- */
 /* p->fs, rs, frame_size replace FS, RS, FRAME_SIZE (qpsk.h:16-23); center_hz replaces CENTER
@@ -42,12 +72,14 @@ int qpsk_dropin_set_device(int device);
 void qpsk_dropin_shutdown(void);
 
 /* ---- rrc_fir.h --------------------------------------------------------- */
-void rrc_fir(complex float memory[], complex float sample[], int length); /* rrc_fir.h:16 */
+void rrc_fir(qpsk_dropin_cfloat memory[], qpsk_dropin_cfloat sample[], int length); /* rrc_fir.h:16 */
 void rrc_make(float fs, float rs, float alpha);                           /* rrc_fir.h:17 */
 
 /* ---- costas_loop.h ----------------------------------------------------- */
 void create_control_loop(float loop_bw, float min_freq, float max_freq);  /* costas_loop.h:16 */
+#ifndef __cplusplus
 float phase_detector(complex float sample);                               /* costas_loop.h:17 */
+#endif
 void update_gains(void);                                                  /* costas_loop.h:18 */
 void advance_loop(float error);                                           /* costas_loop.h:19 */
 void phase_wrap(void);                                                    /* costas_loop.h:20 */
@@ -70,20 +102,28 @@ float get_max_freq(void);                                                 /* cos
 float get_min_freq(void);                                                 /* costas_loop.h:43 */
 
 /* ---- algorithms/fft.h -------------------------------------------------- */
-#define QPSK_NFFT 512                                                     /* fft.h:44 */
-void fft(complex double *in, complex double *out);                        /* fft.h:46 */
-void fftn(complex double *in, complex double *out, int n);                /* fft.h:47 */
-void ifft(complex double *in, complex double *out);                       /* fft.h:48 */
-void ifftn(complex double *in, complex double *out, int n);               /* fft.h:49 */
+#define QPSK_NFFT NFFT
+void fft(qpsk_dropin_cdouble *in, qpsk_dropin_cdouble *out);              /* fft.h:46 */
+void fftn(qpsk_dropin_cdouble *in, qpsk_dropin_cdouble *out, int n);      /* fft.h:47 */
+void ifft(qpsk_dropin_cdouble *in, qpsk_dropin_cdouble *out);             /* fft.h:48 */
+void ifftn(qpsk_dropin_cdouble *in, qpsk_dropin_cdouble *out, int n);     /* fft.h:49 */
 
 /* ---- qpsk.c (file-static there, exported equivalents here) ------------- */
+#ifndef QPSK_DROPIN_PRIMITIVES_ONLY
+#ifndef __cplusplus
 void qpsk_demod(complex float symbol, int bits[]);                        /* qpsk.c:24,74-79 */
+#endif
 void rx_frame(int16_t in[]);                                              /* qpsk.c:25,88-218 */
+#endif
 
 /* what rx_frame() leaves in the reference's globals (qpsk.c:41,51) */
-const complex float *qpsk_dropin_costas_frame(void);   /* costas_frame[FRAME_SIZE/CYCLES] */
+const qpsk_dropin_cfloat *qpsk_dropin_costas_frame(void);   /* costas_frame[FRAME_SIZE/CYCLES] */
 const uint8_t *qpsk_dropin_symbols(void);              /* (bits[1]<<1)|bits[0] per symbol, qpsk.c:209 */
 float qpsk_dropin_offset_freq(void);                   /* fbb_offset_freq, qpsk.c:217 */
 int qpsk_dropin_timing_index(void);                    /* index, qpsk.c:105,173-180 */
+
+#ifdef __cplusplus
+}
+#endif
 
 #endif /* QPSK_DROPIN_H */
