@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <map>
 #include <vector>
 
@@ -69,7 +70,7 @@ struct Tuning {
     int fir_generic = -1;                             /* full-rate rrc_fir(): 1 = the compiler-scheduled rrc_fir_kernel also for symmetric taps */
     int stream_scan = -1;                             /* streams from PCM, histogram timing: 1 = stream_scan_kernel (mixer + filter + scan) whatever the stream count, 0 = never */
     int stream_poll = -1;                             /* qpsk_streams_rx_pcm_host on the one-launch kernel: 0 = wait with hipStreamSynchronize instead of watching the kernel's counter */
-    int stream_block = -1;                            /* streams: 0 = never the one-launch-per-block kernel (streamblock.hip), 1 = whenever the shape allows, unset: up to 1024 streams */
+    int stream_block = -1;                            /* streams: 0 = never the one-launch-per-block kernel (streamblock.hip), 1 = whenever the shape allows, unset: by samples per block of all streams (stream_block_ok: 3.5 M for PCM, 0.4 M for complex input at CYCLES 8) */
     int stream_carrier = -1;                          /* stream_scan_kernel on PCM: 0 = every stream runs its own carrier (mixer wave) even while all streams share one */
     int fft_fused = -1;                               /* FFT timing estimate: 0 = always a launch of its own (1 / unset: inside rx_fused_pipe_kernel's launch for full workgroups) */
 };
@@ -134,6 +135,7 @@ struct qpsk_ctx {
     unsigned carrier_blocks = 0;        /* blocks taken from the tables since the reset (which of the two holds the current one) */
     unsigned carrier_scans = 0;         /* stream_scan_kernel launches among them (its relay counter, kernels.h) */
     float *carrier_pending = nullptr;   /* the table stream_scan_kernel has begun: the loop kernel of the same call finishes it (carrier.h) */
+    bool streams_poisoned = false;      /* a stream call failed between its launches (or a kernel gave up): carried state is undefined until the next reset */
     /* host-pointer streaming call (qpsk_streams_rx_pcm_host: what the drop-in rx_frame() uses): pinned staging on the
      * host, matching arena on the device; sized for nstreams blocks */
     unsigned char *h_stage = nullptr, *d_stage = nullptr;
@@ -169,8 +171,15 @@ static int ensure(qpsk_ctx *c, DevBuf &b, size_t bytes)
 static int check_status(qpsk_ctx *c)
 {
     const int st = __atomic_exchange_n(c->h_status, 0, __ATOMIC_ACQ_REL);
-    if (st == STATUS_PIPE_TIMEOUT)
+    if (st == STATUS_PIPE_TIMEOUT) {
+        /* a kernel gave up a bounded wait: running streams (their carried state, the shared carrier's relay counter) are undefined from here */
+        if (c->nstreams > 0) {
+            c->streams_poisoned = true;
+            c->carrier_shared = false;
+            c->carrier_pending = nullptr;
+        }
         return fail(QPSK_ERR_HIP, "pipeline kernel: producer/consumer wait timed out; results of the calls since the last synchronisation are invalid");
+    }
     if (st == STATUS_PHASE_RANGE)
         return fail(QPSK_ERR_RANGE, "Costas loop phase beyond the bounded 2 pi wrap (input amplitude far outside the modem's range; "
                                     "the reference's phase_wrap() would spin or hang, costas_loop.c:61-67); results of the calls since the last synchronisation are invalid");
@@ -318,6 +327,7 @@ static void free_streams(qpsk_ctx *c)
     hipFree(c->s_memory); hipFree(c->s_dec); hipFree(c->s_loop); hipFree(c->s_mixer); hipFree(c->s_ctab); hipFree(c->s_cstate);
     c->s_memory = c->s_dec = c->s_loop = c->s_mixer = c->s_ctab = c->s_cstate = nullptr;
     c->carrier_shared = false;
+    c->carrier_pending = nullptr;       /* points into s_ctab */
     c->nstreams = 0;
 }
 
@@ -560,28 +570,6 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     const bool pipe_ok = c->cycles == pipe_cycles() && (c->prm.frame_size % 2) == 0 && (frame_pitch % 2) == 0 &&
                          ((uintptr_t)d_in % 16) == 0 && nbw * pipe_frames(1) <= 64 &&
                          tuned(c->tune.generic, 0) == 0;
-    /* BASELINE config 3's shape -- FFT timing estimate, a batch that fills rx_fused_pipe_kernel's 16-frame workgroups -- runs the
-     * estimate inside the receive launch (rx_fused.hip); every other shape launches timing_fft_kernel in front.  The conditions
-     * restate which kernel and geometry the code below will pick. */
-    bool fused_fft = false;
-    double *est_tw = nullptr, *est_cs = nullptr;
-    if (c->prm.timing_mode == QPSK_TIMING_FFT && pipe_ok && nbw == 1 && tuned(c->tune.fft_fused, 1) != 0 &&
-        tuned(c->tune.pipe_v, nframes > 16 * c->ncu ? 2 : 1) == 1 && c->prm.frame_size >= timing_fft_first() + timing_fft_nfft() &&
-        !(tuned(c->tune.pipe_variant, 0) & (128 | 4))) {
-        const int full = pipe_max_nf();
-        int nf = 1;
-        while (nf < full && (long long)c->ncu * pipe_frames(nf) < nframes) nf++;
-        nf = tuned(c->tune.pipe_nf, nf);
-        if (nf >= full && pipe_lds_bytes(full, nbw) <= (size_t)MAX_LDS_BYTES) {
-            int rt = fft_timing_tables(c, &est_tw, &est_cs);
-            if (rt) return rt;
-            fused_fft = true;
-        }
-    }
-    const int32_t *idx = nullptr;
-    int rc = timing_indices(c, d_in, (size_t)frame_pitch, nframes, &idx, fused_fft);
-    if (rc) return rc;
-
     FusedArgs a{};
     a.x = reinterpret_cast<const float2 *>(d_in);
     a.frame_pitch = (size_t)frame_pitch;
@@ -590,14 +578,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     a.cycles = c->cycles;
     a.nsym = c->nsym;
     pick_tiling(c, nframes, nbw, &a.G, &a.S);
-    a.index = idx;
     a.fixed_index = c->prm.fixed_index;
-    if (fused_fft) {
-        a.est_tw = reinterpret_cast<const double2 *>(est_tw);
-        a.est_cs = reinterpret_cast<const double2 *>(est_cs);
-        a.index_out = d_index ? (int32_t *)c->index.p : nullptr;
-        if (d_index) idx = (const int32_t *)c->index.p;      /* copied to the caller's array behind the launch, below */
-    }
     a.dbg = tuned(c->tune.pipe_variant, 0) & PIPE_VARIANT_MASK;
     a.taps = c->d_taps;
     a.gains = c->d_gains;
@@ -611,15 +592,25 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     a.costas = reinterpret_cast<float2 *>(d_costas);
     a.hz = d_hz;
     a.status = c->d_status;
-    /* Two pipeline kernels [measured, DESIGN.md 4.1]: up to 16 frames per CU the recurrence is the limit and the
-     * 16-frame workgroups of rx_fused_pipe_kernel (serial wave alone on its SIMD, four-symbol FIR lanes) are 2 %
-     * ahead; above that the filter is the limit and rx_pipe2_kernel's 32-frame workgroups win by 20 % */
+
+    /* ---- which kernel takes the batch: decided ONCE, here, as a plan; the timing estimate's placement (below) reads the plan and
+     * the launches execute it -- nothing restates the choice (round 4 restated it for the in-launch FFT estimate and missed a
+     * tuning key: QPSK_PIPE_G above 16 sent the batch to rx_lean_kernel with no index computed).
+     * Two pipeline kernels [measured, DESIGN.md 4.1]: up to 16 frames per CU the recurrence is the limit and the 16-frame workgroups
+     * of rx_fused_pipe_kernel (serial wave alone on its SIMD, four-symbol FIR lanes) are ahead; above that the filter is the limit
+     * and the 32-frame workgroups of rx_lean_kernel / rx_pipe2_kernel win by 20 %. */
+    enum { K_GENERIC, K_FUSED_PIPE, K_PIPE2, K_LEAN };
+    struct Plan {
+        int kind = K_GENERIC, nframes = 0, G = 0, nf = 0;
+        unsigned long long layout = 0;
+    };
     const int pipe_v = tuned(c->tune.pipe_v, nframes > 16 * c->ncu ? 2 : 1);
     /* the pipeline kernels of rounds 1-2 (and the generic chunked kernel): any shape */
-    auto launch_general = [&](const FusedArgs &a, int nframes, int pv) -> int {
+    auto plan_general = [&](int nfr, int pv, Plan *pl) -> int {
+        pl->nframes = nfr;
         if (pipe_ok && pv == 2) {
             /* rx_pipe2_kernel: up to 32 frames per workgroup, one workgroup per CU when the batch allows it */
-            int G = (nframes + c->ncu - 1) / c->ncu;
+            int G = (nfr + c->ncu - 1) / c->ncu;
             if (G > pipe2_max_frames()) G = pipe2_max_frames();
             G = tuned(c->tune.pipe_g, G);
             if (G > pipe2_max_frames()) G = pipe2_max_frames();
@@ -645,8 +636,9 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
                     G--;
                 }
             }
-            KERNEL_TRY(launch_rx_pipe2(a, G, layout, c->d_status, c->stream));
-            c->last_kernel = "rx_pipe2_kernel";
+            pl->kind = K_PIPE2;
+            pl->G = G;
+            pl->layout = layout;
         } else if (pipe_ok) {
             /* 16-frame workgroups (four FIR waves of four frames, fewer when the batch gives a CU fewer frames); a batch
              * above 16 frames per CU would run them in rounds */
@@ -655,25 +647,25 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
             };
             const int full = pipe_max_nf();
             int nf = 1;
-            while (nf < full && (long long)c->ncu * pipe_frames(nf) < nframes) nf++;
+            while (nf < full && (long long)c->ncu * pipe_frames(nf) < nfr) nf++;
             nf = tuned(c->tune.pipe_nf, nf);
             if (nf < 1) nf = 1;
             if (nf > full) nf = full;
             while (nf > 1 && !fits(nf)) nf--;
             if (!fits(nf))
                 return fail(QPSK_ERR_ARG, "pipeline geometry does not fit: nf %d, %d loops per frame", nf, nbw);
-            KERNEL_TRY(launch_rx_fused_pipe(a, nf, c->d_status, c->stream));
-            c->last_kernel = a.est_tw ? "rx_fused_pipe_kernel (FFT timing estimate inside the launch)" : "rx_fused_pipe_kernel";
+            pl->kind = K_FUSED_PIPE;
+            pl->nf = nf;
         } else {
-            KERNEL_TRY(launch_rx_fused(a, c->stream));
-            c->last_kernel = "rx_fused_kernel";
+            pl->kind = K_GENERIC;
         }
         return QPSK_OK;
     };
     /* rx_lean_kernel (the FIR waves' chunk loop as one hand-written stream) serves whole even workgroups of frames made of
      * whole chunks, one loop per frame, symmetric filter, no costas_frame[] dump; a batch's last partial workgroup and every
      * other shape go to the kernels above.  QPSK_PIPE_V = 3 asks for it at any batch size, 1 / 2 for the older kernels. */
-    bool served = false;
+    Plan main_pl, rem_pl;
+    bool lean = false;
     if (pipe_ok && c->taps_symmetric && (pipe_v == 3 || c->tune.pipe_v < 0)) {
         int G = (nframes + c->ncu - 1) / c->ncu;
         G = tuned(c->tune.pipe_g, G);
@@ -692,31 +684,91 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
             int nwin = 0, units = 0;
             for (int w = 1; w < 16; w++) { const int cw = (int)((layout >> (4 * w)) & 15); units += cw; nwin += cw != 0; }
             if (units == G / 2 && lean_lds_bytes(G, nwin) <= (size_t)MAX_LDS_BYTES) {
-                KERNEL_TRY(launch_rx_lean(am, G, layout, c->d_status, c->stream));
-                c->last_kernel = "rx_lean_kernel";
-                served = true;
+                lean = true;
+                main_pl.kind = K_LEAN;
+                main_pl.nframes = am.nframes;
+                main_pl.G = G;
+                main_pl.layout = layout;
                 const int rem = nframes - am.nframes;
                 if (rem > 0) {      /* the last partial workgroup */
-                    FusedArgs ar = a;
-                    const size_t o = (size_t)am.nframes;
-                    ar.nframes = rem;
-                    ar.x += o * a.frame_pitch;
-                    if (ar.index) ar.index += o;
-                    ar.sym += o * (size_t)a.nsym;
-                    if (ar.freq) ar.freq += o;
-                    if (ar.phase) ar.phase += o;
-                    if (ar.hz) ar.hz += o;
-                    const char *lk = c->last_kernel;
-                    int rc2 = launch_general(ar, rem, rem > 16 * c->ncu ? 2 : 1);
-                    if (rc2) return rc2;
-                    c->last_kernel = lk;
+                    int rp = plan_general(rem, rem > 16 * c->ncu ? 2 : 1, &rem_pl);
+                    if (rp) return rp;
                 }
             }
         }
     }
-    if (!served) {
-        int rc2 = launch_general(a, nframes, pipe_v == 3 ? (nframes > 16 * c->ncu ? 2 : 1) : pipe_v);
+    if (!lean) {
+        int rp = plan_general(nframes, pipe_v == 3 ? (nframes > 16 * c->ncu ? 2 : 1) : pipe_v, &main_pl);
+        if (rp) return rp;
+    }
+
+    /* ---- the timing estimate.  BASELINE config 3's shape -- FFT estimate, ONE launch of rx_fused_pipe_kernel in full 16-frame
+     * workgroups, as the plan says -- runs the estimate inside the receive launch (rx_fused.hip); every other plan gets its indices
+     * from a launch in front (timing_fft_kernel / timing_scan_kernel / ...). */
+    bool fused_fft = false;
+    double *est_tw = nullptr, *est_cs = nullptr;
+    if (c->prm.timing_mode == QPSK_TIMING_FFT && main_pl.kind == K_FUSED_PIPE && main_pl.nf == pipe_max_nf() && rem_pl.nframes == 0 &&
+        nbw == 1 && tuned(c->tune.fft_fused, 1) != 0 && c->prm.frame_size >= timing_fft_first() + timing_fft_nfft() &&
+        !(tuned(c->tune.pipe_variant, 0) & (128 | 4))) {
+        int rt = fft_timing_tables(c, &est_tw, &est_cs);
+        if (rt) return rt;
+        fused_fft = true;
+    }
+    const int32_t *idx = nullptr;
+    int rc = timing_indices(c, d_in, (size_t)frame_pitch, nframes, &idx, fused_fft);
+    if (rc) return rc;
+    a.index = idx;
+    if (fused_fft) {
+        a.est_tw = reinterpret_cast<const double2 *>(est_tw);
+        a.est_cs = reinterpret_cast<const double2 *>(est_cs);
+        a.index_out = d_index ? (int32_t *)c->index.p : nullptr;
+        if (d_index) idx = (const int32_t *)c->index.p;      /* copied to the caller's array behind the launch, below */
+    }
+
+    /* ---- the launches */
+    auto execute = [&](const FusedArgs &fa, const Plan &pl) -> int {
+        /* only rx_fused_pipe_kernel's full workgroups look at est_tw; any other kernel would demodulate with fixed_index */
+        if (fa.est_tw && !(pl.kind == K_FUSED_PIPE && pl.nf == pipe_max_nf()))
+            return fail(QPSK_ERR_STATE, "internal: in-launch FFT timing estimate planned for a kernel that has none");
+        switch (pl.kind) {
+        case K_LEAN:
+            KERNEL_TRY(launch_rx_lean(fa, pl.G, pl.layout, c->d_status, c->stream));
+            c->last_kernel = "rx_lean_kernel";
+            break;
+        case K_PIPE2:
+            KERNEL_TRY(launch_rx_pipe2(fa, pl.G, pl.layout, c->d_status, c->stream));
+            c->last_kernel = "rx_pipe2_kernel";
+            break;
+        case K_FUSED_PIPE:
+            KERNEL_TRY(launch_rx_fused_pipe(fa, pl.nf, c->d_status, c->stream));
+            c->last_kernel = fa.est_tw ? "rx_fused_pipe_kernel (FFT timing estimate inside the launch)" : "rx_fused_pipe_kernel";
+            break;
+        default:
+            KERNEL_TRY(launch_rx_fused(fa, c->stream));
+            c->last_kernel = "rx_fused_kernel";
+        }
+        return QPSK_OK;
+    };
+    {
+        FusedArgs am = a;
+        am.nframes = main_pl.nframes;
+        int rc2 = execute(am, main_pl);
         if (rc2) return rc2;
+        if (rem_pl.nframes > 0) {
+            FusedArgs ar = a;
+            const size_t o = (size_t)main_pl.nframes;
+            ar.nframes = rem_pl.nframes;
+            ar.x += o * a.frame_pitch;
+            if (ar.index) ar.index += o;
+            ar.sym += o * (size_t)a.nsym;
+            if (ar.freq) ar.freq += o;
+            if (ar.phase) ar.phase += o;
+            if (ar.hz) ar.hz += o;
+            const char *lk = c->last_kernel;
+            rc2 = execute(ar, rem_pl);
+            if (rc2) return rc2;
+            c->last_kernel = lk;
+        }
     }
     if (d_index) {
         if (idx)
@@ -979,6 +1031,8 @@ int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
     c->carrier_shared = false;
     c->carrier_blocks = 0;
     c->carrier_scans = 0;
+    c->carrier_pending = nullptr;
+    c->streams_poisoned = false;
     if (c->prm.frame_size % 2 == 0 && (stream_scan_ok(c, true, true) || stream_block_ok(c))) {      /* (a kernel that uses it would take these streams) */
         KERNEL_TRY(launch_carrier_table(c->s_cstate, c->s_ctab, c->prm.frame_size, false, c->stream));
         c->carrier_shared = true;
@@ -1054,7 +1108,6 @@ static int streams_block_launch(qpsk_ctx *c, const int16_t *pcm, const float *cp
             a.ctab = reinterpret_cast<const float2 *>(c->s_ctab + L2 * (c->carrier_blocks & 1u));
             a.ctab_next = reinterpret_cast<float2 *>(c->s_ctab + L2 * ((c->carrier_blocks + 1u) & 1u));
             a.cstate = c->s_cstate;
-            c->carrier_blocks++;
         } else if (int rb = carrier_to_streams(c)) {
             return rb;
         }
@@ -1082,6 +1135,7 @@ static int streams_block_launch(qpsk_ctx *c, const int16_t *pcm, const float *cp
     a.status = c->d_status;
     a.done = count ? c->d_done : nullptr;
     KERNEL_TRY(launch_stream_block(a, c->nstreams, c->stream, inl));
+    if (a.ctab) c->carrier_blocks++;      /* the tables flip only once the launch that fills the next one is in the stream */
     c->last_kernel = "stream_block_kernel";
     return QPSK_OK;
 }
@@ -1171,14 +1225,18 @@ static int streams_scanned(qpsk_ctx *c, const int16_t *d_pcm, const float *d_cpl
         if (c->carrier_shared && tuned(c->tune.stream_carrier, 1) != 0) {
             ctab = c->s_ctab + 2 * (size_t)L * (c->carrier_blocks & 1u);
             ctab_next = c->s_ctab + 2 * (size_t)L * ((c->carrier_blocks + 1u) & 1u);
-            c->carrier_blocks++;
-            c->carrier_pending = ctab_next;
         } else if (int rb = carrier_to_streams(c)) {
             return rb;
         }
     }
     KERNEL_TRY(launch_stream_scan(d_pcm, d_cplx, c->s_mixer, c->s_memory, (float *)c->filtered.p, c->d_taps, (int32_t *)c->index.p, n, L,
-                                  c->d_status, c->stream, ctab, ctab_next, c->s_cstate, ctab ? (int)c->carrier_scans++ : 0, c->cycles));
+                                  c->d_status, c->stream, ctab, ctab_next, c->s_cstate, ctab ? c->carrier_scans : 0u, c->cycles));
+    if (ctab) {      /* the bookkeeping describes launches that ARE in the stream: the tables flip, the relay's turn advances, the rest of the
+                      * next table is owed (a failure between here and the launch that pays it poisons the streams: stream_call_done) */
+        c->carrier_blocks++;
+        c->carrier_scans++;
+        c->carrier_pending = ctab_next;
+    }
     const int rc = streams_from_filter(c, nullptr, true, d_sym, d_freq, d_phase, d_costas, d_index, true);
     if (c->carrier_pending) {      /* the loop kernel was never reached: the table is finished all the same */
         float *tab = c->carrier_pending;
@@ -1188,12 +1246,32 @@ static int streams_scanned(qpsk_ctx *c, const int16_t *d_pcm, const float *d_cpl
     return rc;
 }
 
-int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *d_freq, float *d_phase,
-                         float *d_costas, int32_t *d_index)
+/* A stream call enqueues several launches and keeps host-side books about them (which carrier table is current, the relay's turn, a
+ * table half built).  If it fails between its launches -- or a kernel reports that it gave up (QPSK_ERR_HIP from the status word) -- the
+ * carried state of the streams is undefined: the shared carrier is dropped and every later stream call is refused until
+ * qpsk_streams_reset().  Argument errors and flagged NUMBERS (QPSK_ERR_RANGE: NaN samples, a phase beyond the bounded wrap) do not
+ * poison: the kernels completed and the state is what the reference's would be or fenced as documented. */
+static int stream_call_done(qpsk_ctx *c, int rc)
 {
-    if (!c || !d_in) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_cplx: null argument");
+    if (rc == QPSK_ERR_HIP || rc == QPSK_ERR_ALLOC) {
+        c->streams_poisoned = true;
+        c->carrier_shared = false;
+        c->carrier_pending = nullptr;
+    }
+    return rc;
+}
+
+static int streams_usable(qpsk_ctx *c, const char *who)
+{
     if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
-    if (bind(c)) return QPSK_ERR_HIP;
+    if (c->streams_poisoned)
+        return fail(QPSK_ERR_STATE, "%s: an earlier stream call failed between its launches; the streams' carried state is undefined until qpsk_streams_reset()", who);
+    return QPSK_OK;
+}
+
+static int streams_rx_cplx_impl(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *d_freq, float *d_phase,
+                                float *d_costas, int32_t *d_index)
+{
     const bool scan = stream_scan_ok(c, false, false) && ((uintptr_t)d_in % 16) == 0;
     if (d_sym && stream_block_ok(c, false) && !prefer_stream_scan(c, scan)) {
         if (int rb = streams_block_launch(c, nullptr, d_in, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
@@ -1204,12 +1282,18 @@ int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *
     return streams_from_filter(c, d_in, false, d_sym, d_freq, d_phase, d_costas, d_index);
 }
 
-int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float *d_freq, float *d_phase,
-                        float *d_costas, int32_t *d_index)
+int qpsk_streams_rx_cplx(qpsk_ctx *c, const float *d_in, uint8_t *d_sym, float *d_freq, float *d_phase,
+                         float *d_costas, int32_t *d_index)
 {
-    if (!c || !d_pcm) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_pcm: null argument");
-    if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
+    if (!c || !d_in) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_cplx: null argument");
+    if (int ru = streams_usable(c, "qpsk_streams_rx_cplx")) return ru;
     if (bind(c)) return QPSK_ERR_HIP;
+    return stream_call_done(c, streams_rx_cplx_impl(c, d_in, d_sym, d_freq, d_phase, d_costas, d_index));
+}
+
+static int streams_rx_pcm_impl(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float *d_freq, float *d_phase,
+                               float *d_costas, int32_t *d_index)
+{
     const bool scan = stream_scan_ok(c, true, c->carrier_shared && tuned(c->tune.stream_carrier, 1) != 0) && ((uintptr_t)d_pcm % 4) == 0;
     if (d_sym && stream_block_ok(c) && !prefer_stream_scan(c, scan)) {
         if (int rb = streams_block_launch(c, d_pcm, nullptr, nullptr, nullptr, d_sym, d_costas, d_index)) return rb;
@@ -1223,7 +1307,16 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
     /* qpsk.c:114-120 */
     if (int rb = carrier_to_streams(c)) return rb;
     KERNEL_TRY(launch_mixer(d_pcm, (float *)c->mixed.p, c->s_mixer, n, L, c->stream));
-    return qpsk_streams_rx_cplx(c, (const float *)c->mixed.p, d_sym, d_freq, d_phase, d_costas, d_index);
+    return streams_rx_cplx_impl(c, (const float *)c->mixed.p, d_sym, d_freq, d_phase, d_costas, d_index);
+}
+
+int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float *d_freq, float *d_phase,
+                        float *d_costas, int32_t *d_index)
+{
+    if (!c || !d_pcm) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_pcm: null argument");
+    if (int ru = streams_usable(c, "qpsk_streams_rx_pcm")) return ru;
+    if (bind(c)) return QPSK_ERR_HIP;
+    return stream_call_done(c, streams_rx_pcm_impl(c, d_pcm, d_sym, d_freq, d_phase, d_costas, d_index));
 }
 
 /*
@@ -1237,11 +1330,26 @@ int qpsk_streams_rx_pcm(qpsk_ctx *c, const int16_t *d_pcm, uint8_t *d_sym, float
  *   h_sym [nstreams][nsym] uint8                h_costas [nstreams][nsym][2] float, may be NULL
  *   h_index [nstreams] int32, may be NULL
  */
+static int streams_rx_pcm_host_impl(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io, uint8_t *h_sym, float *h_costas, int32_t *h_index);
 int qpsk_streams_rx_pcm_host(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io, uint8_t *h_sym, float *h_costas, int32_t *h_index)
 {
     if (!c || !h_pcm || !h_sym) return fail(QPSK_ERR_ARG, "qpsk_streams_rx_pcm_host: null argument");
-    if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
+    if (int ru = streams_usable(c, "qpsk_streams_rx_pcm_host")) return ru;
     if (bind(c)) return QPSK_ERR_HIP;
+    return stream_call_done(c, streams_rx_pcm_host_impl(c, h_pcm, h_loop_io, h_sym, h_costas, h_index));
+}
+
+static inline void cpu_relax(void)
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
+
+static int streams_rx_pcm_host_impl(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io, uint8_t *h_sym, float *h_costas, int32_t *h_index)
+{
     const size_t n = (size_t)c->nstreams, L = (size_t)c->prm.frame_size, N = (size_t)c->nsym;
     /* arena layout, every part 16-byte aligned: in = [loop 8n | pcm 2nL], out = [sym nN | costas 8nN | loop 8n | index 4n] */
     auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
@@ -1283,13 +1391,32 @@ int qpsk_streams_rx_pcm_host(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io
             return rb;
         if (poll) {
             /* the kernel's two waves per stream count themselves off in pinned memory behind their last store: watching that word
-             * is quicker than the stream's completion signal.  Bounded: after ~2 s the ordinary synchronisation takes over. */
+             * is quicker than the stream's completion signal.  Bounded by the WALL CLOCK (2 s, looked at every 4096 spins): then the
+             * ordinary synchronisation takes over, and a counter that is still short after THAT is an error -- the kernel did not run to
+             * its end, its results are not in the staging buffer -- with the expectation put back in step with the counter. */
             c->done_expect += 2u * (unsigned)n;
             const volatile unsigned *dn = c->h_done;
-            long spins = 0;
-            while ((int)(*dn - c->done_expect) < 0 && ++spins < 400000000L) __builtin_ia32_pause();
+            struct timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            for (unsigned spins = 0; (int)(*dn - c->done_expect) < 0; ) {
+                cpu_relax();
+                if ((++spins & 4095u) == 0) {
+                    clock_gettime(CLOCK_MONOTONIC, &t1);
+                    if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 2.0) break;
+                }
+            }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            if ((int)(*dn - c->done_expect) < 0) HIP_TRY(hipStreamSynchronize(c->stream));
+            if ((int)(*dn - c->done_expect) < 0) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                if ((int)(*dn - c->done_expect) < 0) {
+                    const unsigned have = *dn, want = c->done_expect;
+                    c->done_expect = have;
+                    (void)check_status(c);      /* take the kernel's own word, if it left one, out of the status word */
+                    return fail(QPSK_ERR_HIP, "stream_block_kernel: %u of %u waves reported completion; the block's results are invalid",
+                                2u * (unsigned)n - (want - have), 2u * (unsigned)n);
+                }
+            }
         } else {
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
@@ -1306,7 +1433,7 @@ int qpsk_streams_rx_pcm_host(qpsk_ctx *c, const int16_t *h_pcm, float *h_loop_io
     uint8_t *d_sym = c->d_stage + o_sym;
     float *d_cos = h_costas ? (float *)(c->d_stage + o_cos) : nullptr;
     int32_t *d_idx = (int32_t *)(c->d_stage + o_idx);
-    int rc = qpsk_streams_rx_pcm(c, (const int16_t *)(c->d_stage + o_pcm), d_sym, nullptr, nullptr, d_cos, d_idx);
+    int rc = streams_rx_pcm_impl(c, (const int16_t *)(c->d_stage + o_pcm), d_sym, nullptr, nullptr, d_cos, d_idx);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_stage + o_lout, c->s_loop, 8 * n, hipMemcpyDeviceToDevice, c->stream));
     /* one copy down: from the symbols to the index (costas_frame[] in between travels even when it is not wanted

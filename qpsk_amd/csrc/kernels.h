@@ -176,9 +176,9 @@ int stream_scan_tile(void);
 int prepare_stream_scan(void);
 int launch_stream_scan(const int16_t *pcm, const float *x, float *mixer, float *memory, float *yout, const float *taps, int32_t *index,
                        int nstreams, int frame_size, int *status, hipStream_t s, const float *ctab = nullptr, float *ctab_next = nullptr,
-                       float *cstate = nullptr, int cseq = 0, int cycles = 8);
+                       float *cstate = nullptr, unsigned cseq = 0, int cycles = 8);
 /* the shared carrier of MODE 2 (streamscan.hip): cstate [8] = {phase the next table starts from, fbb_rx_rect, phase the last table
- * started from, the relay counter of stream_scan_kernel's spare waves (an int: zero it with cseq = 0), unused}; a table = the frame_size
+ * started from, the relay counter of stream_scan_kernel's spare waves (an unsigned int, wrapping: zero it with cseq = 0), unused}; a table = the frame_size
  * phases of one block; cseq = the number of MODE 2 launches since that counter was zeroed.  ctab != NULL selects MODE 2: this block's phases from ctab,
  * the next block's into ctab_next (by a spare wave of workgroup 0), cstate advanced; the per-stream mixer[] is then not touched */
 int launch_carrier_table(float *cstate, float *tab, int frame_size, bool rest_only, hipStream_t s);   /* whole table, or what stream_scan_kernel left (carrier.h) */

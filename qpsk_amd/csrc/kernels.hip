@@ -711,6 +711,7 @@ __global__ void sincos_hash_kernel(uint32_t first, uint32_t count, unsigned long
 
 int launch_rx_fused(const FusedArgs &a, hipStream_t s)
 {
+    if (a.est_tw) return (int)hipErrorInvalidValue;    /* no in-launch timing estimate in this kernel: it would use fixed_index */
     const int blocks = (a.nframes + a.G - 1) / a.G;
     const size_t lds = fused_lds_bytes(a.G, a.S, a.cycles, a.nbw);
     hipLaunchKernelGGL(rx_fused_kernel, dim3(blocks), dim3(FUSED_THREADS), lds, s, a);

@@ -1417,6 +1417,7 @@ unsigned long long pipe2_default_layout(int NU)
 int launch_rx_pipe2(const FusedArgs &a0, int G, unsigned long long layout, int *status, hipStream_t s)
 {
     using namespace pipe2;
+    if (a0.est_tw) return (int)hipErrorInvalidValue;   /* no in-launch timing estimate in this kernel: it would use fixed_index */
     FusedArgs a = a0;
     const int NU = (G + UF - 1) / UF;
     int units = 0, nwin = 0, hw = 1;
@@ -1663,6 +1664,7 @@ bool lean_shape_ok(const FusedArgs &a, int G)
 int launch_rx_lean(const FusedArgs &a0, int G, unsigned long long layout, int *status, hipStream_t s)
 {
     using namespace pipe2;
+    if (a0.est_tw) return (int)hipErrorInvalidValue;   /* no in-launch timing estimate in this kernel: it would use fixed_index */
     FusedArgs a = a0;
     int units = 0, nwin = 0, hw = 1;
     for (int w = 1; w < 16; w++) {

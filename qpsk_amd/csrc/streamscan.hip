@@ -114,7 +114,7 @@ template <int MODE>
 __global__ void __launch_bounds__(MODE ? sscan::THREADS : sscan::THREADS - 64)
 stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x, float *mixer, float2 *memory, float2 *__restrict__ yout,
                    const float *__restrict__ taps_g, int32_t *index, int nstreams, int frame_size, int *status,
-                   const float2 *__restrict__ ctab, float2 *ctab_next, float *cstate, int cseq, int cycles)
+                   const float2 *__restrict__ ctab, float2 *ctab_next, float *cstate, unsigned cseq, int cycles)
 {
     using namespace sscan;
     constexpr bool PCM = MODE != 0;
@@ -145,8 +145,10 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
         if ((int)blockIdx.x < parts && lane == 0) {
             const int split = carrier_split(frame_size), per = ((split + parts - 1) / parts + 3) & ~3;
             const int from = min((int)blockIdx.x * per, split), to = min(from + per, split);
-            int *ctr = reinterpret_cast<int *>(cstate + 6);
-            const int turn = cseq * parts + (int)blockIdx.x;
+            /* unsigned: the launch count since the reset wraps modulo 2^32 with defined arithmetic (2^28 launches of a signed turn were
+             * ~3 h of 4096 x 512 blocks); parts is the same at every launch between two resets, so the sequence stays consistent */
+            unsigned *ctr = reinterpret_cast<unsigned *>(cstate + 6);
+            const unsigned turn = cseq * (unsigned)parts + blockIdx.x;
             int spins = 0;
             bool ok = true;
             while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != turn) {
@@ -158,7 +160,7 @@ stream_scan_kernel(const int16_t *__restrict__ pcm, const float2 *__restrict__ x
                 __builtin_amdgcn_s_setprio(3);
                 carrier_block(cstate, ctab_next, frame_size, from, to);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_store(ctr, turn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ctr, turn + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 __hip_atomic_store(status, STATUS_PIPE_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -434,10 +436,10 @@ int launch_carrier_broadcast(const float *cstate, float *mixer, int nstreams, hi
     return (int)hipGetLastError();
 }
 
-/* CYCLES = 8, frame_size % 256 == 0, symmetric taps, 16-byte aligned yout (the caller checks); exactly one of pcm (4-byte aligned rows;
+/* CYCLES = 8 or 4, frame_size % 256 == 0, symmetric taps, 16-byte aligned yout (the caller checks); exactly one of pcm (4-byte aligned rows;
  * mixer state updated) and x (16-byte aligned complex blocks); yout [nstreams][cycles][frame_size / cycles], cycles 8 or 4 */
 int launch_stream_scan(const int16_t *pcm, const float *x, float *mixer, float *memory, float *yout, const float *taps, int32_t *index,
-                       int nstreams, int frame_size, int *status, hipStream_t s, const float *ctab, float *ctab_next, float *cstate, int cseq,
+                       int nstreams, int frame_size, int *status, hipStream_t s, const float *ctab, float *ctab_next, float *cstate, unsigned cseq,
                        int cycles)
 {
     using namespace sscan;
@@ -453,11 +455,11 @@ int launch_stream_scan(const int16_t *pcm, const float *x, float *mixer, float *
                            reinterpret_cast<const float2 *>(ctab), reinterpret_cast<float2 *>(ctab_next), cstate, cseq, cycles);
     else if (pcm)
         hipLaunchKernelGGL(stream_scan_kernel<1>, grid, dim3(THREADS), LDS_BYTES, s, pcm, nullptr, mixer, reinterpret_cast<float2 *>(memory),
-                           reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status, nullptr, nullptr, nullptr, 0, cycles);
+                           reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status, nullptr, nullptr, nullptr, 0u, cycles);
     else
         hipLaunchKernelGGL(stream_scan_kernel<0>, grid, dim3(THREADS - 64), LDS_BYTES, s, nullptr, reinterpret_cast<const float2 *>(x), mixer,
                            reinterpret_cast<float2 *>(memory), reinterpret_cast<float2 *>(yout), taps, index, nstreams, frame_size, status,
-                           nullptr, nullptr, nullptr, 0, cycles);
+                           nullptr, nullptr, nullptr, 0u, cycles);
     return (int)hipGetLastError();
 }
 

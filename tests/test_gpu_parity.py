@@ -118,6 +118,30 @@ def test_rx_batch_fft_timing(oracle, fs, rs, L, F):
     assert np.all(want["index"][:F - 2] == 126 % m.cycles)
 
 
+@pytest.mark.parametrize("tune,kernel", [(dict(pipe_g=32), "rx_lean_kernel"), (dict(pipe_g=20), "rx_lean_kernel"),
+                                         (dict(pipe_v=2), "rx_pipe2_kernel"), (dict(pipe_v=3), "rx_lean_kernel"),
+                                         (dict(pipe_nf=2), "rx_fused_pipe_kernel"), (dict(fused_generic=1), "rx_fused_kernel"),
+                                         (dict(fft_fused=0), "rx_fused_pipe_kernel"), (dict(pipe_dbg=128), "rx_fused_pipe_kernel"),
+                                         (dict(), "rx_fused_pipe_kernel (FFT timing estimate inside the launch)")])
+def test_fft_timing_under_every_geometry_key(oracle, tune, kernel):
+    """No tuning key may change a result (include/qpsk_hip.h).  Round 4's host code restated the kernel choice to decide whether the
+    FFT estimate runs inside the receive launch and missed QPSK_PIPE_G: with G above 16 the batch went to rx_lean_kernel, which has no
+    estimate, with no index computed -- silently wrong symbols.  The plan is now made once and the estimate's placement reads it: the
+    FFT-timed batch under every key that moves it to another kernel, against the oracle, the index included."""
+    from oracle.pyoracle import TIMING_FFT
+    fs, rs, L, F = 19200.0, 2400.0, 1024, 4096        # 4096 frames = 16 per CU: the in-launch estimate's shape when nothing is set
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT, fixed_index=3)     # a fixed_index that is NOT the estimate (6)
+    x, _ = make_frames(F, L, m.cycles, m.taps, fs, offset_hz=30.0, base_seed=77, noise=0.03)
+    x[5] = random_frames(1, L, seed=9)[0]
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FFT, fixed_index=3)
+    m.tune(**tune)
+    got = m.rx_batch(x)
+    m.sync()
+    assert m.last_kernel() == kernel, m.last_kernel()
+    assert_batch_equal(got, want)
+    assert np.all(want["index"][:5] == 6)
+
+
 def test_rx_batch_tilings_agree(oracle):
     """results do not depend on how frames are grouped into workgroups / chunks"""
     fs, rs, L, F = 19200.0, 2400.0, 2048, 50
