@@ -62,24 +62,25 @@ def synth_frames_gpu(torch, dev, nframes, taps, seed, offset_hz=50.0):
     return out
 
 
-def tx_frames_gpu(torch, dev, qpsk_amd, nframes, seed, offset_hz=50.0, local=0):
+def tx_frames_gpu(torch, dev, qpsk_amd, nframes, seed, offset_hz=50.0, local=0, fs=None, rs=None, frame_size=None):
     """The same stimulus from the library's own transmit chain (qpsk.c:225-285): one transmitter per frame,
     random dibits -> qpsk_tx_symbols() = Gray map, zero-stuffing and TX RRC shaping in tx_shape_kernel -> its complex baseband
     output, rotated by the +50 Hz carrier offset the reference tests (qpsk.c:320 against 342).  N2 at the scale it was written
     for: 1 GiB of frames per GPU built in place from 16 MB of symbols, nothing staged from the host.  Returns (F, L, 2) float32."""
+    fs, rs, fl = fs or FS, rs or RS, frame_size or L
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    nsym = L // CYCLES
-    mt = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX, device=local)
+    nsym = fl // int(fs / rs)
+    mt = qpsk_amd.Modem(fs=fs, rs=rs, frame_size=fl, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX, device=local)
     mt.tx_reset(nframes, 0.0)
     sym = torch.randint(0, 4, (nframes, nsym), generator=g, device=dev, dtype=torch.uint8)
     out = mt.tx_symbols(sym, want_pcm=False, want_baseband=True)["baseband"]
     mt.sync()
     mt.close()
-    n = torch.arange(L, device=dev, dtype=torch.float64)
-    ang = 2.0 * np.pi * offset_hz * n / FS
+    n = torch.arange(fl, device=dev, dtype=torch.float64)
+    ang = 2.0 * np.pi * offset_hz * n / fs
     cr, ci = torch.cos(ang).float(), torch.sin(ang).float()
-    chunk = 512
+    chunk = max(1, (512 * 16384) // fl)
     for f0 in range(0, nframes, chunk):
         f1 = min(nframes, f0 + chunk)
         re, im = out[f0:f1, :, 0].clone(), out[f0:f1, :, 1].clone()
@@ -89,23 +90,14 @@ def tx_frames_gpu(torch, dev, qpsk_amd, nframes, seed, offset_hz=50.0, local=0):
 
 
 def cpu_baseline(x_host, taps):
-    """The reference's CPU path timed on this box's host cores, on a bounded sample of the same frames.
-    kind "reference": oracle/_ref (the untouched reference compiled with its own Makefile flags, one core,
-    consecutive rx_frame() calls as in its main loop, qpsk.c:344-354) when that library travelled here;
-    otherwise kind "port": the oracle restatement (-O2), one core."""
+    """The reference's CPU path timed on this box's host cores, on a bounded sample of the same frames (SURVEY 8(d), BASELINE.md 3).
+    `value` = the build's own C restatement of the path (oracle/, proven bit-equal to the reference), gcc -O2 -ffp-contract=off,
+    ONE core -- what travels with the repository and is directly comparable to the single-threaded reference; kind "port".
+    Beside it: the same on all host cores (one independent frame per thread, core count stated), and -- when oracle/_ref travelled
+    here (a git-ignored build product of the build container) -- the untouched reference itself at its Makefile's flags (no -O), one
+    core, consecutive rx_frame() calls as in its main loop (qpsk.c:344-354), as `reference_makefile_flags_msps`."""
     from oracle.pyoracle import Oracle, Reference, TIMING_HIST, ref_available
     nsamp = x_host.shape[0] * x_host.shape[1]
-    out = {}
-    have_ref = bool(ref_available("c1"))
-    if have_ref:
-        ref = Reference("c1")
-        ref.reset()
-        t0 = time.perf_counter()
-        for f in range(x_host.shape[0]):
-            ref.rx_cplx(x_host[f])
-        dt = time.perf_counter() - t0
-        out = dict(value=nsamp / dt / 1e6, unit="Msamples/s", cores=1, kind="reference",
-                   sample="%d frames x %d samples, consecutive rx_frame() calls on oracle/_ref (gcc -std=c11, no -O, as the reference Makefile)" % x_host.shape[:2])
     orc = Oracle()
     t0 = time.perf_counter()
     orc.rx_batch(x_host, FS, RS, timing_mode=TIMING_HIST, threads=1)
@@ -117,15 +109,23 @@ def cpu_baseline(x_host, taps):
     t0 = time.perf_counter()
     orc.rx_batch(x_host, FS, RS, timing_mode=TIMING_HIST, threads=ncores)
     dtn = time.perf_counter() - t0
-    port = dict(port_1core_msps=nsamp / dt1 / 1e6, port_allcores_msps=nsamp / dtn / 1e6, port_cores=ncores,
-                port_flags="gcc -O2 -ffp-contract=off, full-rate FIR + histogram timing + Costas (the reference's work)")
-    if not out:
-        out = dict(value=port["port_1core_msps"], unit="Msamples/s", cores=1, kind="port",
-                   sample="%d frames x %d samples, oracle restatement" % x_host.shape[:2])
-    out.update(port)
-    # oracle/_ref/*.so is built in the build container from /root/reference and is git-ignored: on a checkout where it did not
-    # travel the line's kind silently becomes "port" -- say which it was
-    out["ref_so"] = "present" if have_ref else "absent (kind falls back to the oracle port)"
+    out = dict(value=nsamp / dt1 / 1e6, unit="Msamples/s", cores=1, kind="port",
+               sample="%d frames x %d samples of the timed batch; oracle restatement: full-rate rrc_fir() + histogram timing + Costas + slicer "
+                      "(the reference's work per rx_frame() call)" % x_host.shape[:2],
+               flags="gcc -O2 -ffp-contract=off (results are optimisation-level independent once contraction is off: tests/test_oracle_vs_ref.py)",
+               port_1core_msps=nsamp / dt1 / 1e6, port_allcores_msps=nsamp / dtn / 1e6, port_cores=ncores)
+    have_ref = bool(ref_available("c1"))
+    if have_ref:
+        nref = min(x_host.shape[0], 512)        # -O0: 2.9 Msamples/s, 512 frames = 3 s
+        ref = Reference("c1")
+        ref.reset()
+        t0 = time.perf_counter()
+        for f in range(nref):
+            ref.rx_cplx(x_host[f])
+        dt = time.perf_counter() - t0
+        out["reference_makefile_flags_msps"] = nref * x_host.shape[1] / dt / 1e6
+        out["reference_sample"] = "%d frames, oracle/_ref (the untouched reference, gcc -std=c11, no -O, as its Makefile), 1 core" % nref
+    out["ref_so"] = "present" if have_ref else "absent (oracle/_ref is built only where /root/reference exists)"
     return out
 
 
@@ -204,8 +204,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=None,
                     help="frames per GPU per step (default: 4096 = config 2 on one GPU, 8192 = config 4's per-GPU share on several)")
-    ap.add_argument("--cpu-frames", type=int, default=2048,
-                    help="frames of the CPU baseline sample (0 = skip); 2048 = half a batch, ~12 s of the reference on one core")
+    ap.add_argument("--cpu-frames", type=int, default=4096,
+                    help="frames of the CPU baseline sample (0 = skip); 4096 = the whole config-2 batch: ~4 s of the -O2 port on one core, "
+                         "then all cores, then 512 frames of the -O0 reference build when it is present")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="N = 1, config 2 only: skip BASELINE configs[4] (1200 baud, 2^20 samples per frame, 11 loop bandwidths; key config5)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-shard", action="store_true",
                     help="N = 1, config 2 only: skip the extra measurement of the 8192-frame per-GPU share (key shard_8192)")
@@ -348,6 +351,10 @@ def main():
             dist.destroy_process_group()
         return
 
+    import hashlib
+    lib_file = qpsk_amd.lib_path()
+    lib_sha256 = hashlib.sha256(open(lib_file, "rb").read()).hexdigest()
+
     def traffic_of(F_):
         """PMC bytes per launch of this shape's kernel from an EARLIER rocprofv3 --pmc session of this command
         (profiles/traffic.json, tools/collect_profiles.py) -- a constant of the code version profiled, not a counter
@@ -357,8 +364,12 @@ def main():
             tj = json.load(open(tpath))
             tj = tj.get("shapes", {}).get("%dx%d" % (F_, L), tj)
             if tj.get("frames") == F_ and tj.get("frame_size") == L:
+                sha_prof = tj.get("library_sha256")
                 return tj.get("hbm_bytes_per_launch"), {
                     "file": "profiles/traffic.json", "from": tj.get("source"),
+                    # the counters belong to ONE build of the library: the one whose hash the profiling session stored
+                    "library_sha256_profiled": sha_prof,
+                    "traffic_matches_library": (bool(sha_prof) and sha_prof == lib_sha256),
                     "file_mtime": time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(tpath))),
                     "kernel_profiled": tj.get("kernel"),
                     "note": "PMC FETCH_SIZE x 2 + WRITE_SIZE of an earlier profiling session, not a counter of this run"}
@@ -377,8 +388,6 @@ def main():
                 "operation_mix_ceiling": {"input_gbs": [4500.0, 4800.0], "source": "profiles/r03_power_ceiling.txt "
                                           "(tools/ubench_valu_power.hip under tools/power_probe.py, an earlier session)"}}
 
-    import hashlib
-    lib_file = qpsk_amd.lib_path()
     ndistinct = distinct_devices(idents)
     samples_per_step = world * F * L
     value = samples_per_step * args.steps / elapsed / 1e6
@@ -405,15 +414,22 @@ def main():
                    "single_gpu_rate_at_this_shape": ("this line's value" if world == 1 else "the N = 1 line's shard_8192.msamples_per_s")},
         "roofline": rl,
         "library": {"path": os.path.relpath(lib_file, ROOT) if lib_file.startswith(ROOT) else lib_file,
-                    "sha256": hashlib.sha256(open(lib_file, "rb").read()).hexdigest(),
+                    "sha256": lib_sha256,
                     "override_QPSK_HIP_LIB": bool(os.environ.get("QPSK_HIP_LIB")), "version": qpsk_amd.version()},
     }
     parity = {"hz_frames_checked": hz_n_all, "hz_out_of_range": hz_bad_all, "mean_freq_hz": hz_mean}
     if not args.no_parity:       # parity gate of the same run (rank 0's shard): bits against the oracle
         from oracle.pyoracle import Oracle, TIMING_FIXED
-        npar = min(256, F)
+        # EVERY frame of the timed batch (round 4 checked 256 of 4096): the oracle's fixed-offset path is the decimating filter + the
+        # loop, 56 Msamples/s on one core -- 16 threads take config 2's 67 M samples in a fraction of a second
+        npar = F
         xh = x[:npar].cpu().numpy()
-        want = Oracle().rx_batch(xh, FS, RS, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX)
+        try:
+            nthr = min(16, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            nthr = min(16, os.cpu_count() or 1)
+        want = Oracle().rx_batch(xh, FS, RS, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX, threads=nthr)
+        del xh
         gs, gf, gp = sym[:npar].cpu().numpy(), freq[:npar].cpu().numpy(), phase[:npar].cpu().numpy()
         parity.update({"frames_checked": npar, "symbol_mismatches": int(np.sum(gs != want["sym"])),
                        "freq_bit_mismatches": int(np.sum(gf.view(np.uint32) != want["freq"].view(np.uint32))),
@@ -507,10 +523,57 @@ def main():
                    "hz_frames_checked": n2, "hz_out_of_range": bad2, "mean_freq_hz": mean2})
         if not args.no_parity:
             from oracle.pyoracle import Oracle, TIMING_FIXED
-            xh = x2[:64].cpu().numpy()
-            want = Oracle().rx_batch(xh, FS, RS, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX)
-            sh["symbol_mismatches_64_frames"] = int(np.sum(outs2[0][:64].cpu().numpy() != want["sym"]))
+            xh = x2.cpu().numpy()              # every frame of this batch too
+            want = Oracle().rx_batch(xh, FS, RS, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX, threads=nthr)
+            del xh
+            sh["parity_frames_checked"] = F2
+            sh["symbol_mismatches"] = int(np.sum(outs2[0].cpu().numpy() != want["sym"]))
+            sh["freq_bit_mismatches"] = int(np.sum(outs2[1].cpu().numpy().view(np.uint32) != want["freq"].view(np.uint32)))
         res["shard_8192"] = sh
+    if world == 1 and (args.frames, L) == (FRAMES_1GPU, 16384) and not args.no_config5:
+        # BASELINE configs[4]: "1200-baud / 8x oversample long-frame variant, 1M samples/frame, Costas loop-BW sweep TAU/100-TAU/200" --
+        # FS 9600 / RS 1200, 1,048,576 samples per frame, 11 loop bandwidths TAU/100, TAU/110, ... TAU/200 as independent Costas
+        # chains over ONE filter pass (README.md:12; qpsk_rx_batch_bw).  384 frames (384 x 11 = 4224 chains >= 4096, 3 GiB
+        # of input; the reference gives no count).  A step is one call; 131,072 serial loop steps per chain bound it by construction
+        # (DESIGN.md 4.1.3), so the fraction of the HBM line is reported, not a target.  Gate: 5 frames x 11 loops against the oracle.
+        torch.cuda.empty_cache()
+        fs5, rs5, L5, F5 = 9600.0, 1200.0, 1 << 20, 384
+        bws5 = [np.float32(2.0 * 3.14159265358979323846 / d) for d in range(100, 201, 10)]
+        m5 = qpsk_amd.Modem(fs=fs5, rs=rs5, frame_size=L5, timing_mode=qpsk_amd.TIMING_FIXED, fixed_index=FIXED_INDEX, device=local)
+        x5 = tx_frames_gpu(torch, dev, qpsk_amd, F5, seed=5000, local=local, fs=fs5, rs=rs5, frame_size=L5)
+        torch.cuda.synchronize()
+        steps5, t5, out5 = 5, [], None
+        for r_ in range(steps5 + 1):                      # first call untimed
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out5 = m5.rx_batch_bw(x5, bws5)
+            e1.record()
+            torch.cuda.synchronize()
+            if r_:
+                t5.append(e0.elapsed_time(e1))
+        m5.sync()
+        ms5 = float(np.median(t5))
+        hz5 = out5["freq"].double() * rs5 / (2 * np.pi)
+        c5 = {"workload": "BASELINE configs[4]: %d frames x %d samples, FS %.0f / RS %.0f, %d loop bandwidths TAU/100..TAU/200 per frame over one filter pass, fixed timing offset %d" % (
+                  F5, L5, fs5, rs5, len(bws5), FIXED_INDEX),
+              "kernel": m5.last_kernel(), "steps": steps5, "ms_per_step": ms5, "steps_per_s": 1e3 / ms5,
+              "msamples_per_s": F5 * L5 / ms5 / 1e3, "loop_msteps_per_s": F5 * (L5 // 8) * len(bws5) / ms5 / 1e3,
+              "frac_of_hbm_peak_on_8B_per_sample": BYTES_PER_SAMPLE * F5 * L5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+              "serial_steps_per_chain": L5 // 8, "chains": F5 * len(bws5),
+              "hz_min": float(hz5.min().item()), "hz_max": float(hz5.max().item()),
+              "chains_within_2hz_of_50": int(((hz5 - 50.0).abs() < 2.0).sum().item())}
+        if not args.no_parity:
+            from oracle.pyoracle import Oracle, TIMING_FIXED
+            npar5 = 5
+            want5 = Oracle().rx_batch_bw(x5[:npar5].cpu().numpy(), fs5, rs5, bws5, timing_mode=TIMING_FIXED, fixed_index=FIXED_INDEX)
+            c5["parity_frames_checked"] = npar5
+            c5["symbol_mismatches"] = int(np.sum(out5["sym"][:npar5].cpu().numpy() != want5["sym"]))
+            c5["freq_bit_mismatches"] = int(np.sum(out5["freq"][:npar5].cpu().numpy().view(np.uint32) != want5["freq"].view(np.uint32)))
+            c5["phase_bit_mismatches"] = int(np.sum(out5["phase"][:npar5].cpu().numpy().view(np.uint32) != want5["phase"].view(np.uint32)))
+        res["config5"] = c5
+        m5.close()
+        del x5, out5
+        torch.cuda.empty_cache()
     if world == 1 and (args.frames, L) == (FRAMES_1GPU, 16384) and not args.no_streams:
         # SURVEY 8(f) N1, the reference's real input and call pattern (qpsk.c:88, 344-354), measured beside the headline and NOT part of it:
         #  (a) 4096 running streams, one 16384-sample int16 PCM block each per call (PCM from the library's own transmit chain at +50 Hz):

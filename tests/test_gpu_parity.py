@@ -341,6 +341,27 @@ def test_full_size_config2_properties(oracle):
     assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
 
 
+def test_full_size_config2_bench_stimulus_every_frame(oracle):
+    """the batch bench.py TIMES: config 2 at full size built by the library's own transmit chain (bench.tx_frames_gpu, the default
+    --stimulus tx, rank 0's seed) -- EVERY one of the 4096 frames against the oracle, bit for bit (the oracle's fixed-offset path runs
+    56 Msamples/s per core); the other full-size tests use the torch stimulus and a spread sample"""
+    import torch
+    import bench
+    import qpsk_amd
+    fs, rs, L, F = bench.FS, bench.RS, 16384, 4096
+    dev = torch.device("cuda", 0)
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=bench.FIXED_INDEX)
+    x = bench.tx_frames_gpu(torch, dev, qpsk_amd, F, seed=1000)
+    a = m.rx_batch(x)
+    m.sync()
+    assert m.last_kernel() == "rx_fused_pipe_kernel"
+    want = oracle.rx_batch(x.cpu().numpy(), fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=bench.FIXED_INDEX,
+                           threads=min(16, os.cpu_count() or 1))
+    for k in ("sym", "phase", "freq", "hz"):
+        assert bits_equal(cpu(a[k]), want[k]), k
+    assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
+
+
 def test_full_size_config2_histogram_timing(oracle):
     """the reference's own timing estimate at config 2's full size (4096 x 16384) through the fused scan kernel:
     (a) a spread sample of frames against the oracle in TIMING_HIST mode, bit for bit, index included; (b) every
