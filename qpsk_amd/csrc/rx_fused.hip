@@ -1518,7 +1518,13 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
             w.wr0[ui][ff] = lds_addr(mywin + ff * WS + slot_of(p0)) - 8u * BLK;
             w.wr1[ui][ff] = lds_addr(mywin + ff * WS + slot_of(p0 + 1)) - 8u * BLK;
             if (lane == 0) {
-                const unsigned long long src = (unsigned long long)(a.x + (size_t)fr * a.frame_pitch);
+                size_t fsrc = (size_t)fr;
+#ifdef QPSK_PIPE_PROFILE
+                /* measurement build, dbg bit 21: a workgroup's frames a grid apart instead of adjacent (WRONG frame -> output mapping;
+                 * the visit order of the batch in memory is what is measured) */
+                if (a.dbg & 2097152) fsrc = (size_t)(UF * u + ff) * gridDim.x + blockIdx.x;
+#endif
+                const unsigned long long src = (unsigned long long)(a.x + fsrc * a.frame_pitch);
                 prm[4 * ui + 2 * ff] = (unsigned)src;
                 prm[4 * ui + 2 * ff + 1] = (unsigned)(src >> 32);
             }
@@ -1557,17 +1563,50 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
             printf("wg %3d FIR wave hw %2d (%d units): %d chunks, %llu cycles in the stream; per chunk: samples %u, stage+loads %u, "
                    "filter+gain %u, wait for the loop %u, flush %u, hand-over %u\n", (int)blockIdx.x, hwave, NUW, nchunks, t1 - t0,
                    pf[0] / nchunks, pf[1] / nchunks, pf[2] / nchunks, pf[3] / nchunks, pf[4] / nchunks, pf[5] / nchunks);
-    } else if (a.dbg & (1 | 16384 | 32768 | 65536)) {
+    } else if (a.dbg & 131072) {
+        /* measurement build, round 5: window staging by LDS-DMA (fir_lean_prof_asm.h, variant "dma"; RIGHT results for even
+         * decimation offsets).  The table the stream reads first, left in the still unused window: per (unit, frame) the four
+         * per-lane source byte offsets of its DMAs -- DMA j's lane l fills window slots S0 + 128 j + 2 l, + 1 of the padded image,
+         * S0 = the slot of the chunk's first sample; a lane that lands on a pad pair re-reads its neighbour's samples -- and the
+         * LDS byte address of slot S0. */
+        unsigned *tab = reinterpret_cast<unsigned *>(mywin);
+#pragma unroll
+        for (int ui = 0; ui < NUW; ui++)
+#pragma unroll
+            for (int ff = 0; ff < UF; ff++) {
+                const int k = 2 * ui + ff;
+                const int ix = (int)((ixpack >> (4 * k)) & 15u);
+                const int S0 = slot_of(HIST - ix);
+                for (int j = 0; j < 4; j++) {
+                    const int sl = S0 + 2 * (64 * j + lane);
+                    const int grp = sl / (PAD + PADS);
+                    int r = sl % (PAD + PADS);
+                    if (r >= PAD) r = PAD - 2;
+                    int n = PAD * grp + r - HIST + ix;
+                    if (n > CH - 2) n = CH - 2;
+                    tab[(4 * k + j) * 64 + lane] = 8u * (unsigned)n;
+                }
+                tab[(16 + k) * 64 + lane] = lds_addr(mywin + ff * WS + S0);
+            }
+        if constexpr (NUW == 2)
+            st = fir_lean_loop2_adma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
+        else
+            st = fir_lean_loop1_adma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
+    } else if (a.dbg & (1 | 16384 | 32768 | 65536 | 262144 | 524288 | 1048576)) {
         /* measurement build: streams with a part of the work left out (WRONG results): 1 the filter's multiplies and adds,
-         * 16384 its window reads, 32768 the flush's arithmetic, 65536 the window staging writes -- what each costs in time and
-         * in energy at the board's power limit (one at a time: the first bit set wins) */
+         * 16384 its window reads, 32768 the flush's arithmetic, 65536 the window staging writes, 262144 the symbol stores, 524288 the
+         * hand-over write of the symbols -- what each costs in time and in energy at the board's power limit (one at a time: the
+         * first bit set wins); 1048576: the unit's loads issued frame-alternating (right results) */
 #define QPSK_LEAN_ABLATED(SFX)                                                                                          \
         (NUW == 2 ? fir_lean_loop2_##SFX(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w)    \
                   : fir_lean_loop1_##SFX(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w))
         if (a.dbg & 1) st = QPSK_LEAN_ABLATED(avalu);
         else if (a.dbg & 16384) st = QPSK_LEAN_ABLATED(alds);
         else if (a.dbg & 32768) st = QPSK_LEAN_ABLATED(aflush);
-        else st = QPSK_LEAN_ABLATED(astage);
+        else if (a.dbg & 65536) st = QPSK_LEAN_ABLATED(astage);
+        else if (a.dbg & 262144) st = QPSK_LEAN_ABLATED(astore);
+        else if (a.dbg & 524288) st = QPSK_LEAN_ABLATED(aring);
+        else st = QPSK_LEAN_ABLATED(aorder);
 #undef QPSK_LEAN_ABLATED
     } else
 #endif

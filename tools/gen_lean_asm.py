@@ -63,8 +63,19 @@ WS_SLOTS = 712                         # slots per frame window (rx_fused.hip, l
 PROFILE = False
 # measurement-only streams with a part of the work left out (wrong results; the profile header only): what each part costs in
 # TIME at the board's power limit, i.e. in energy.  "valu": no filter multiplies / adds; "lds": no window reads after the first
-# two blocks; "flush": no sin/cos redo, rotation, slicer arithmetic
+# two blocks; "flush": no sin/cos redo, rotation, slicer arithmetic; "stage": no window staging writes.  Round 5:
+#   "store"  no symbol stores (the flush's global_store_short);        "ring"  no hand-over write of the unit's symbols (counter kept);
+#   "order"  the unit's eight loads issued frame-alternating (1 KB visits instead of 4 KB per frame);
+#   "dma"    window staging by LDS-DMA: blocks 0..2 of a frame's 512 new samples go HBM -> LDS directly (four global_load_lds_dwordx4
+#            per frame, per-lane source offsets that realise the padded window image, the last one on 24 lanes), issued when the
+#            window is free, i.e. behind the filter of the unit before; block 3 -- which is also the next chunk's history -- keeps
+#            the register path (one load, one ds_write_b128, the history registers).  Even decimation offsets only.  This variant
+#            computes the RIGHT result (it is the candidate design, measured before it is adopted).
 ABLATE = None
+# registers of the "dma" variant (the prefetch registers v32..v63 are free there except the block-3 quads v44..47 / v60..63):
+DMA_OFF = [32, 36, 40, 48]      # per (unit, frame) k = 2 ui + ff: four per-lane source byte offsets, one per DMA
+DMA_BASE = 52                   # v52..v55: LDS byte address of the DMA region of frame k (wave-uniform)
+DMA_M0 = 56                     # the compiler's m0, parked
 NPROF = 6            # wait for the samples | stage + issue loads | filter + gain | wait for the loop | flush | hand-over + priority
 PACC, PTMP, PLAST = 160, 166, 167
 
@@ -229,7 +240,7 @@ def stage_frame(e, ui, ff):
         e("v_add_u32_e32 v%d, 0x%x, %s", dst, 4 * BLK_BYTES, base)
         e("v_cmp_gt_u32_e32 vcc, v%d, %%[wlim]", dst)
         e("v_cndmask_b32_e32 v%d, v%d, %%[wpad], vcc", dst, dst)
-    for j in range(4):
+    for j in ((3,) if ABLATE == "dma" else range(4)):
         if ff == 1 and j == 3:
             clamped(P0, wr0)
             e("ds_write_b128 v%d, %s", P0, v4(PRE + 16 * ff + 4 * j))
@@ -260,9 +271,28 @@ def stage_frame(e, ui, ff):
 
 
 def loads(e, u):
-    for ff in range(2):
+    if ABLATE == "dma":
+        for ff in range(2):
+            k = 2 * u + ff
+            e("v_readfirstlane_b32 s%d, v%d", ST0, DMA_BASE + k)
+            e("s_mov_b32 m0, s%d", ST0)
+            for j in range(4):
+                if j == 3:
+                    e("s_mov_b64 exec, 0xffffff")      # slots 384..431 of the 432-slot region: 24 lanes
+                e("s_nop 0")
+                e("global_load_lds_dwordx4 v%d, %s nt", DMA_OFF[k] + j, sp(SRC + 4 * u + 2 * ff))
+                if j < 3:
+                    e("s_add_u32 m0, m0, 0x400")
+            e("s_mov_b64 exec, -1")
+            e("global_load_dwordx4 %s, %%[voff], %s offset:%d nt", v4(PRE + 16 * ff + 12), sp(SRC + 4 * u + 2 * ff), 1024 * 3)
+    elif ABLATE == "order":
         for j in range(4):
-            e("global_load_dwordx4 %s, %%[voff], %s offset:%d nt", v4(PRE + 16 * ff + 4 * j), sp(SRC + 4 * u + 2 * ff), 1024 * j)
+            for ff in range(2):
+                e("global_load_dwordx4 %s, %%[voff], %s offset:%d nt", v4(PRE + 16 * ff + 4 * j), sp(SRC + 4 * u + 2 * ff), 1024 * j)
+    else:
+        for ff in range(2):
+            for j in range(4):
+                e("global_load_dwordx4 %s, %%[voff], %s offset:%d nt", v4(PRE + 16 * ff + 4 * j), sp(SRC + 4 * u + 2 * ff), 1024 * j)
     for ff in range(2):
         s = SRC + 4 * u + 2 * ff
         e("s_add_u32 s%d, s%d, 0x1000", s, s)
@@ -347,7 +377,8 @@ def flush(e, ui):
         e("v_cmp_gt_f32_e32 vcc, 0, v%d", B + 5)
         e("v_addc_co_u32_e64 v%d, vcc, v%d, v%d, vcc", B + 7, B + 7, B + 7)  # (bits[1] << 1) | bits[0]
     e("v_lshl_or_b32 v%d, v%d, 8, v%d", FL, b[1] + 7, b[0] + 7)
-    e("global_store_short %%[symoff], v%d, %s nt", FL, sp(SYMB + 2 * ui))
+    if ABLATE != "store":
+        e("global_store_short %%[symoff], v%d, %s nt", FL, sp(SYMB + 2 * ui))
     e("s_add_u32 s%d, s%d, 64", SYMB + 2 * ui, SYMB + 2 * ui)
     e("s_addc_u32 s%d, s%d, 0", SYMB + 2 * ui + 1, SYMB + 2 * ui + 1)
 
@@ -377,31 +408,40 @@ def unit(e, ui, nuw, packed=True):
     e.place(pr_done)
     stamp(e, 5)
     # ---- the unit's samples: everything issued after their loads is the previous iteration's symbol store, if any
-    w1, w2 = e.label("vm"), e.label("vm")
-    e("s_cmp_eq_u32 s%d, 0", SFL)
-    e("s_cbranch_scc1 %s", w1)
-    e("s_waitcnt vmcnt(1)")
-    e("s_branch %s", w2)
-    e.place(w1)
-    e("s_waitcnt vmcnt(0)")
-    e.place(w2)
+    if ABLATE == "store":
+        e("s_waitcnt vmcnt(0)")
+    else:
+        w1, w2 = e.label("vm"), e.label("vm")
+        e("s_cmp_eq_u32 s%d, 0", SFL)
+        e("s_cbranch_scc1 %s", w1)
+        e("s_waitcnt vmcnt(1)")
+        e("s_branch %s", w2)
+        e.place(w1)
+        e("s_waitcnt vmcnt(0)")
+        e.place(w2)
     stamp(e, 0)
     e("s_mov_b32 s%d, 0", SFL)
     stage_frame(e, ui, 0)
     stage_frame(e, ui, 1)
-    # ---- the next unit's samples, a whole unit ahead
-    if last:
-        skip = e.label("ld")
-        e("s_add_u32 s%d, s%d, 1", ST0, SC)
-        e("s_cmp_ge_u32 s%d, s%d", ST0, SN)
-        e("s_cbranch_scc1 %s", skip)
-        loads(e, nx)
-        e.place(skip)
-    else:
-        loads(e, nx)
+    # ---- the next unit's samples, a whole unit ahead -- into registers; by LDS-DMA they go into the wave's ONE window, so only
+    #      once this unit's filter has read it
+    def next_loads():
+        if last:
+            skip = e.label("ld")
+            e("s_add_u32 s%d, s%d, 1", ST0, SC)
+            e("s_cmp_ge_u32 s%d, s%d", ST0, SN)
+            e("s_cbranch_scc1 %s", skip)
+            loads(e, nx)
+            e.place(skip)
+        else:
+            loads(e, nx)
+    if ABLATE != "dma":
+        next_loads()
     stamp(e, 1)
     # ---- filter, gain
     filter_stream(e, packed)
+    if ABLATE == "dma":
+        next_loads()
     for i in range(4):
         e("v_cvt_f64_f32 %s, v%d", vp(P0 + 2 * i), ACC + i)
     for i in range(4):
@@ -444,7 +484,8 @@ def unit(e, ui, nuw, packed=True):
     e.place(nofl)
     stamp(e, -1)
     # ---- hand-over: the symbols, then the counter (same wave, LDS in order)
-    e("ds_write_b128 v%d, %s", TMP + 2, v4(G))
+    if ABLATE != "ring":
+        e("ds_write_b128 v%d, %s", TMP + 2, v4(G))
     e("s_add_u32 s%d, s%d, 1", ST0, SC)
     e("v_mov_b32_e32 v%d, s%d", TMP + 1, ST0)
     e("s_bfe_u32 s%d, s%d, 0x80010", ST0, SIX)                  # 4 x the wave's first unit number
@@ -469,6 +510,13 @@ def block(nuw, packed=True):
     e("v_readfirstlane_b32 s%d, v%d", SIX, PRE + 13)
     e("v_readfirstlane_b32 s%d, v%d", ST0, PRE + 16)
     e("v_readfirstlane_b32 s%d, v%d", ST1, PRE + 17)
+    if ABLATE == "dma":         # per-lane DMA source offsets and the DMA regions' LDS addresses: a table the kernel left in the (still unused) window
+        e("v_mov_b32_e32 v%d, m0", DMA_M0)
+        for k in range(2 * nuw):
+            for j in range(4):
+                e("ds_read_b32 v%d, %%[tab] offset:%d", DMA_OFF[k] + j, 256 * (4 * k + j))
+            e("ds_read_b32 v%d, %%[tab] offset:%d", DMA_BASE + k, 256 * (16 + k))
+        e("s_waitcnt lgkmcnt(0)")
     loads(e, 0)                 # the first unit's samples at once: their HBM latency covers the tap loads and the set-up below
     for i in range(4):
         e("s_load_dwordx16 s[%d:%d], %s, 0x%x", TAP0 + 16 * i, TAP0 + 16 * i + 15, sp(ST0), 64 * i)
@@ -500,6 +548,9 @@ def block(nuw, packed=True):
     e.place("Lexit_%=")
     e("s_setprio 0")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if ABLATE == "dma":
+        e("v_readfirstlane_b32 s%d, v%d", ST0, DMA_M0)
+        e("s_mov_b32 m0, s%d", ST0)
     if PROFILE and not ABLATE:
         for k in range(NPROF):
             e("v_mov_b32_e32 %%[pf%d], v%d", k, PACC + k)
@@ -512,6 +563,9 @@ def emit_function(nuw, packed=True):
     ops = ['[prm] "v"(prm_addr)', '[rd] "v"(rd_addr)', '[voff] "v"(voff)', '[symoff] "v"(symoff)', '[smem] "v"(smem_addr)',
            '[wlim] "v"(w.wlim)', '[wpad] "v"(w.wpad)']
     args = ["unsigned prm_addr", "unsigned rd_addr", "unsigned voff", "unsigned symoff", "unsigned smem_addr"]
+    if ABLATE == "dma":
+        ops.append('[tab] "v"(tab_addr)')
+        args.append("unsigned tab_addr")
     for ui in range(nuw):
         for ff in range(2):
             ops += ['[w0_%d%d] "v"(w.wr0[%d][%d])' % (ui, ff, ui, ff), '[w1_%d%d] "v"(w.wr1[%d][%d])' % (ui, ff, ui, ff)]
@@ -556,7 +610,7 @@ constexpr int FIR_LEAN_NPROF = %d;
     print(emit_function(1))
     print(emit_function(2))
     global ABLATE
-    for ABLATE in ("valu", "lds", "flush", "stage"):
+    for ABLATE in ("valu", "lds", "flush", "stage", "store", "ring", "order", "dma"):
         print(emit_function(1))
         print(emit_function(2))
     ABLATE = None

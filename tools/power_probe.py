@@ -23,14 +23,20 @@ x = bench.synth_frames_gpu(torch, dev, frames, m.taps, seed=1)
 sym = torch.empty((frames, m.nsym), dtype=torch.uint8, device=dev)
 fr = torch.empty((frames,), dtype=torch.float32, device=dev); ph = torch.empty_like(fr)
 if dbg: m.tune(pipe_dbg=dbg)
-if tune: m.tune(**{kv.split("=")[0]: int(kv.split("=")[1], 0) for kv in tune.split(",")})
+kv = {k.split("=")[0]: int(k.split("=")[1], 0) for k in tune.split(",")} if tune else {}
+pitch = kv.pop("pitch", 0)       # pitch=16448: frames 16384 + 64 samples apart (qpsk_rx_batch_pitched) instead of packed
+if pitch:
+    xp = torch.zeros((frames, pitch, 2), dtype=torch.float32, device=dev)
+    xp[:, :bench.L] = x
+    x = xp
+if kv: m.tune(**kv)
 print("ready", flush=True)
 t0 = time.time(); n = 0
 while time.time() - t0 < secs:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(500):
-        m.rx_batch_raw(x, frames, sym, fr, ph)
+        m.rx_batch_raw(x, frames, sym, fr, ph, pitch=pitch)
     e1.record(); torch.cuda.synchronize(); n += 500
     last = e0.elapsed_time(e1) / 500
 print("child: %%d frames, dbg %%d %%s, %%s, %%.4f ms per launch (last 500), %%d launches" %% (frames, dbg, tune, m.last_kernel(), last, n), flush=True)
