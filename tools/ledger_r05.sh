@@ -11,6 +11,6 @@ QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so timeout -k 10 200 python3 tools/check_
 echo "== measurement build.  QPSK_PIPE_DBG: 0 the kernel; 131072 LDS-DMA window staging; 65536 no staging writes; 262144 no symbol stores; 524288 no hand-over"
 echo "   write of the symbols; 1048576 loads frame-alternating (1 KB visits); 2097152 a workgroup's frames a grid apart; 3 floor (no filter arithmetic, no recurrence);"
 echo "   pitch=16448: frames 16384 + 64 samples apart"
-QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so timeout -k 10 900 python3 tools/power_probe.py 8192 8192:131072 8192:65536 8192:262144 8192:524288 8192:1048576 8192:2097152 8192:0:pitch=16448 8192:3 8192:131075 8192:1048579 8192:2097155 8192:3:pitch=16448 8192:262147 8192:524291 8192 2>&1 | grep -v amdgpu.ids
+QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so timeout -k 10 900 python3 tools/power_probe.py 8192 8192:131072 8192:65536 8192:262144 8192:524288 8192:1048576 8192:2097152 8192:0:pitch=16448 8192:3 8192:2097155 8192:3:pitch=16448 8192 2>&1 | grep -v amdgpu.ids
 } > $O 2>&1
 tail -5 $O
