@@ -30,5 +30,7 @@ for L, F, ix in ((1024, 8192, 6), (2048, 4608, 0), (1536, 8192, 2), (1024, 5120,
         ok = all(np.array_equal(got[k].cpu().numpy().view(np.uint8), want[k].view(np.uint8)) for k in ("sym", "freq", "phase"))
         print("L %5d F %5d index %d dbg %8d %-16s %s" % (L, F, ix, dbg, m.last_kernel(), "bit-exact" if ok else "DIFFERS"), flush=True)
         bad += not ok
+        if not ok:
+            sys.exit(1)         # one wrong variant: stop, nothing further touches the GPU
     m.close()
 sys.exit(1 if bad else 0)

@@ -274,8 +274,8 @@ def loads(e, u):
     if ABLATE == "dma":
         for ff in range(2):
             k = 2 * u + ff
-            e("v_readfirstlane_b32 s%d, v%d", ST0, DMA_BASE + k)
-            e("s_mov_b32 m0, s%d", ST0)
+            e("v_readfirstlane_b32 s%d, v%d", ST3, DMA_BASE + k)     # (not ST0/ST1: the prologue keeps the taps pointer there)
+            e("s_mov_b32 m0, s%d", ST3)
             for j in range(4):
                 if j == 3:
                     e("s_mov_b64 exec, 0xffffff")      # slots 384..431 of the 432-slot region: 24 lanes

@@ -5,12 +5,17 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/ledger_r05.txt
 [ -f qpsk_amd/libqpsk_hip_prof.so ] || make -C qpsk_amd/csrc profile > gpurun_out/prof_build.log 2>&1
+echo "== correctness of the variants that claim the right result (LDS-DMA staging, load order)" > $O
+QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so timeout -k 10 200 python3 tools/check_lean_variants.py 2>&1 | grep -v amdgpu.ids >> $O
+if [ ${PIPESTATUS[0]} -ne 0 ] || grep -q "Memory access fault\|DIFFERS" $O; then
+    echo "variant check FAILED: nothing else is run in this call" >> $O
+    tail -20 $O
+    exit 1
+fi
 {
-echo "== correctness of the variants that claim the right result (LDS-DMA staging, load order)"
-QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so timeout -k 10 200 python3 tools/check_lean_variants.py 2>&1 | grep -v amdgpu.ids
 echo "== measurement build.  QPSK_PIPE_DBG: 0 the kernel; 131072 LDS-DMA window staging; 65536 no staging writes; 262144 no symbol stores; 524288 no hand-over"
 echo "   write of the symbols; 1048576 loads frame-alternating (1 KB visits); 2097152 a workgroup's frames a grid apart; 3 floor (no filter arithmetic, no recurrence);"
 echo "   pitch=16448: frames 16384 + 64 samples apart"
-QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so timeout -k 10 900 python3 tools/power_probe.py 8192 8192:131072 8192:65536 8192:262144 8192:524288 8192:1048576 8192:2097152 8192:0:pitch=16448 8192:3 8192:2097155 8192:3:pitch=16448 8192 2>&1 | grep -v amdgpu.ids
-} > $O 2>&1
+QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so timeout -k 10 900 python3 tools/power_probe.py 8192 8192:131072 8192:65536 8192 8192:131072 2>&1 | grep -v amdgpu.ids
+} >> $O 2>&1
 tail -5 $O
