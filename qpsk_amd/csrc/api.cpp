@@ -72,6 +72,7 @@ struct Tuning {
     int stream_poll = -1;                             /* qpsk_streams_rx_pcm_host on the one-launch kernel: 0 = wait with hipStreamSynchronize instead of watching the kernel's counter */
     int stream_block = -1;                            /* streams: 0 = never the one-launch-per-block kernel (streamblock.hip), 1 = whenever the shape allows, unset: by samples per block of all streams (stream_block_ok: 3.5 M for PCM, 0.4 M for complex input at CYCLES 8) */
     int stream_carrier = -1;                          /* stream_scan_kernel on PCM: 0 = every stream runs its own carrier (mixer wave) even while all streams share one */
+    int lean_dma = -1;                                /* rx_lean_kernel: 0 = window staging through registers even where LDS-DMA applies (even decimation offsets) */
     int fft_fused = -1;                               /* FFT timing estimate: 0 = always a launch of its own (1 / unset: inside rx_fused_pipe_kernel's launch for full workgroups) */
 };
 
@@ -84,6 +85,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
     {"QPSK_FIR_GENERIC", &Tuning::fir_generic}, {"QPSK_FFT_FUSED", &Tuning::fft_fused},
     {"QPSK_STREAM_BLOCK", &Tuning::stream_block}, {"QPSK_STREAM_POLL", &Tuning::stream_poll},
     {"QPSK_STREAM_SCAN", &Tuning::stream_scan}, {"QPSK_STREAM_CARRIER", &Tuning::stream_carrier},
+    {"QPSK_LEAN_DMA", &Tuning::lean_dma},
 };
 
 /* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
@@ -580,6 +582,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     pick_tiling(c, nframes, nbw, &a.G, &a.S);
     a.fixed_index = c->prm.fixed_index;
     a.dbg = tuned(c->tune.pipe_variant, 0) & PIPE_VARIANT_MASK;
+    a.lean_dma = tuned(c->tune.lean_dma, 1) != 0;
     a.taps = c->d_taps;
     a.gains = c->d_gains;
     a.nbw = nbw;

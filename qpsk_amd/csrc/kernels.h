@@ -34,6 +34,8 @@ struct FusedArgs {
      * candidate phases (both host-built, api.cpp); index_out [nframes] or NULL receives the indices.  NULL = off */
     const double2 *est_tw, *est_cs;
     int32_t *index_out;
+    int lean_dma;           /* rx_lean_kernel: 1 = FIR waves whose frames all have an even decimation offset stage their windows by LDS-DMA
+                               (fir_lean_asm.h, the _dma loops); 0 = always through registers.  Same bits either way ("QPSK_LEAN_DMA") */
     int dbg;                /* layout variants of the pipeline kernel, all bit-exact (qpsk_ctx_set_tuning "QPSK_PIPE_DBG"):
                                4 no spare waves, 8 C++ Costas step, 16 serial wave chunk by chunk (no stream across the ring hand-overs), 64 FIR waves that share a SIMD keep their hardware order (16-frame kernel), 128 one lane mapping for all FIR waves (the plain
                                layout).  Measurement build only (-DQPSK_PIPE_PROFILE; masked off by api.cpp otherwise):

@@ -1563,35 +1563,6 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
             printf("wg %3d FIR wave hw %2d (%d units): %d chunks, %llu cycles in the stream; per chunk: samples %u, stage+loads %u, "
                    "filter+gain %u, wait for the loop %u, flush %u, hand-over %u\n", (int)blockIdx.x, hwave, NUW, nchunks, t1 - t0,
                    pf[0] / nchunks, pf[1] / nchunks, pf[2] / nchunks, pf[3] / nchunks, pf[4] / nchunks, pf[5] / nchunks);
-    } else if (a.dbg & 131072) {
-        /* measurement build, round 5: window staging by LDS-DMA (fir_lean_prof_asm.h, variant "dma"; RIGHT results for even
-         * decimation offsets).  The table the stream reads first, left in the still unused window: per (unit, frame) the four
-         * per-lane source byte offsets of its DMAs -- DMA j's lane l fills window slots S0 + 128 j + 2 l, + 1 of the padded image,
-         * S0 = the slot of the chunk's first sample; a lane that lands on a pad pair re-reads its neighbour's samples -- and the
-         * LDS byte address of slot S0. */
-        unsigned *tab = reinterpret_cast<unsigned *>(mywin);
-#pragma unroll
-        for (int ui = 0; ui < NUW; ui++)
-#pragma unroll
-            for (int ff = 0; ff < UF; ff++) {
-                const int k = 2 * ui + ff;
-                const int ix = (int)((ixpack >> (4 * k)) & 15u);
-                const int S0 = slot_of(HIST - ix);
-                for (int j = 0; j < 4; j++) {
-                    const int sl = S0 + 2 * (64 * j + lane);
-                    const int grp = sl / (PAD + PADS);
-                    int r = sl % (PAD + PADS);
-                    if (r >= PAD) r = PAD - 2;
-                    int n = PAD * grp + r - HIST + ix;
-                    if (n > CH - 2) n = CH - 2;
-                    tab[(4 * k + j) * 64 + lane] = 8u * (unsigned)n;
-                }
-                tab[(16 + k) * 64 + lane] = lds_addr(mywin + ff * WS + S0);
-            }
-        if constexpr (NUW == 2)
-            st = fir_lean_loop2_adma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
-        else
-            st = fir_lean_loop1_adma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
     } else if (a.dbg & (1 | 16384 | 32768 | 65536 | 262144 | 524288 | 1048576)) {
         /* measurement build: streams with a part of the work left out (WRONG results): 1 the filter's multiplies and adds,
          * 16384 its window reads, 32768 the flush's arithmetic, 65536 the window staging writes, 262144 the symbol stores, 524288 the
@@ -1610,7 +1581,36 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
 #undef QPSK_LEAN_ABLATED
     } else
 #endif
-    if constexpr (NUW == 2)
+    if (a.lean_dma && (ixpack & 0x1111u) == 0) {
+        /* Window staging by LDS-DMA (fir_lean_asm.h, the _dma loops): every decimation offset of the wave's frames is even, so the
+         * 16-byte pairs of the window image are 16-byte pairs of the input.  The table the stream reads first, left in the still
+         * unused window: per frame k = 2 unit + frame the four per-lane source byte offsets of its DMAs -- DMA j's lane l fills
+         * window slots S0 + 128 j + 2 l, + 1 of the padded image (slot_of), S0 = the slot of the chunk's first sample; a lane whose
+         * pair is a pad pair re-reads its neighbour's samples (the same 16 bytes: no extra traffic) -- and the LDS byte address of S0. */
+        unsigned *tab = reinterpret_cast<unsigned *>(mywin);
+#pragma unroll
+        for (int ui = 0; ui < NUW; ui++)
+#pragma unroll
+            for (int ff = 0; ff < UF; ff++) {
+                const int k = 2 * ui + ff;
+                const int ix = (int)((ixpack >> (4 * k)) & 15u);
+                const int S0 = slot_of(HIST - ix);
+                for (int j = 0; j < 4; j++) {
+                    const int sl = S0 + 2 * (64 * j + lane);
+                    const int grp = sl / (PAD + PADS);
+                    int r = sl % (PAD + PADS);
+                    if (r >= PAD) r = PAD - 2;
+                    int n = PAD * grp + r - HIST + ix;
+                    if (n > CH - 2) n = CH - 2;          /* lanes the last DMA masks off */
+                    tab[(4 * k + j) * 64 + lane] = 8u * (unsigned)n;
+                }
+                tab[(16 + k) * 64 + lane] = lds_addr(mywin + ff * WS + S0);
+            }
+        if constexpr (NUW == 2)
+            st = fir_lean_loop2_dma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
+        else
+            st = fir_lean_loop1_dma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
+    } else if constexpr (NUW == 2)
         st = fir_lean_loop2(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w);
     else
         st = fir_lean_loop1(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w);

@@ -341,6 +341,45 @@ def test_full_size_config2_properties(oracle):
     assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
 
 
+@pytest.mark.parametrize("mode", ["fixed_even", "fixed_odd", "per_frame"])
+def test_lean_kernel_window_staging_by_dma_and_through_registers(oracle, mode):
+    """rx_lean_kernel stages a FIR wave's windows by LDS-DMA when every decimation offset of the wave's four frames is even (16-byte pairs
+    of the window image are 16-byte pairs of the input) and through registers otherwise -- a per-wave choice, so one launch mixes both
+    when the offsets come per frame (histogram timing: random frames get every index).  Every case against the oracle, and DMA off
+    (QPSK_LEAN_DMA = 0) equal to DMA on."""
+    from oracle.pyoracle import TIMING_HIST as TH
+    fs, rs, L, F = 19200.0, 2400.0, 1536, 8192 + 64
+    if mode == "per_frame":
+        m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TH)
+        # noise, clean modem frames, tones and decaying bursts: their amplitude histograms put the reference's index (qpsk.c:173-180)
+        # on every value 0..7, so FIR waves with four even offsets (DMA) and waves with an odd one (registers) sit side by side
+        x = random_frames(F, L, seed=31)
+        clean, _ = make_frames(F // 2, L, 8, m.taps, fs, offset_hz=25.0, base_seed=8, noise=0.05)
+        x[::2] = clean
+        rng, n = np.random.default_rng(5), np.arange(L)
+        for f in range(1, F, 4):
+            z = np.exp(1j * rng.uniform(0.01, 0.5) * n) * rng.uniform(0.2, 3)
+            x[f, :, 0], x[f, :, 1] = z.real, z.imag
+        for f in range(3, F, 8):
+            z = np.exp(-n / rng.uniform(50, 800)) * (rng.standard_normal(L) + 1j * rng.standard_normal(L))
+            x[f, :, 0], x[f, :, 1] = z.real, z.imag
+        want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TH, threads=min(16, os.cpu_count() or 1))
+        assert len(np.unique(want["index"])) >= 4 and np.any(want["index"] % 2 == 1) and np.any(want["index"] % 2 == 0)
+    else:
+        ix = 4 if mode == "fixed_even" else 3
+        m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=ix)
+        x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=25.0, base_seed=9, noise=0.05)
+        want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=ix, threads=min(16, os.cpu_count() or 1))
+    import torch
+    xd = torch.from_numpy(x).cuda()
+    for dma in (None, 0):
+        m.tune(lean_dma=dma)
+        got = m.rx_batch(xd)
+        m.sync()
+        assert m.last_kernel() == "rx_lean_kernel", m.last_kernel()
+        assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz"))
+
+
 def test_full_size_config2_bench_stimulus_every_frame(oracle):
     """the batch bench.py TIMES: config 2 at full size built by the library's own transmit chain (bench.tx_frames_gpu, the default
     --stimulus tx, rank 0's seed) -- EVERY one of the 4096 frames against the oracle, bit for bit (the oracle's fixed-offset path runs

@@ -66,13 +66,15 @@ PROFILE = False
 # two blocks; "flush": no sin/cos redo, rotation, slicer arithmetic; "stage": no window staging writes.  Round 5:
 #   "store"  no symbol stores (the flush's global_store_short);        "ring"  no hand-over write of the unit's symbols (counter kept);
 #   "order"  the unit's eight loads issued frame-alternating (1 KB visits instead of 4 KB per frame);
-#   "dma"    window staging by LDS-DMA: blocks 0..2 of a frame's 512 new samples go HBM -> LDS directly (four global_load_lds_dwordx4
+#   DMA = True (not an ablation: fir_lean_loop*_dma of the product header)
+#            window staging by LDS-DMA: blocks 0..2 of a frame's 512 new samples go HBM -> LDS directly (four global_load_lds_dwordx4
 #            per frame, per-lane source offsets that realise the padded window image, the last one on 24 lanes), issued when the
 #            window is free, i.e. behind the filter of the unit before; block 3 -- which is also the next chunk's history -- keeps
-#            the register path (one load, one ds_write_b128, the history registers).  Even decimation offsets only.  This variant
-#            computes the RIGHT result (it is the candidate design, measured before it is adopted).
+#            the register path (one load, one ds_write_b128, the history registers).  Even decimation offsets only (16-byte DMA
+#            granules).  [measured, profiles/r05_energy_ledger.txt] bit-exact, 1.7 % less energy per launch at 8192 frames.
 ABLATE = None
-# registers of the "dma" variant (the prefetch registers v32..v63 are free there except the block-3 quads v44..47 / v60..63):
+DMA = False          # the stream with LDS-DMA window staging (fir_lean_loop*_dma), see "dma" above: product code since round 5
+# registers of the DMA stream (the prefetch registers v32..v63 are free there except the block-3 quads v44..47 / v60..63):
 DMA_OFF = [32, 36, 40, 48]      # per (unit, frame) k = 2 ui + ff: four per-lane source byte offsets, one per DMA
 DMA_BASE = 52                   # v52..v55: LDS byte address of the DMA region of frame k (wave-uniform)
 DMA_M0 = 56                     # the compiler's m0, parked
@@ -240,7 +242,7 @@ def stage_frame(e, ui, ff):
         e("v_add_u32_e32 v%d, 0x%x, %s", dst, 4 * BLK_BYTES, base)
         e("v_cmp_gt_u32_e32 vcc, v%d, %%[wlim]", dst)
         e("v_cndmask_b32_e32 v%d, v%d, %%[wpad], vcc", dst, dst)
-    for j in ((3,) if ABLATE == "dma" else range(4)):
+    for j in ((3,) if DMA else range(4)):
         if ff == 1 and j == 3:
             clamped(P0, wr0)
             e("ds_write_b128 v%d, %s", P0, v4(PRE + 16 * ff + 4 * j))
@@ -271,7 +273,7 @@ def stage_frame(e, ui, ff):
 
 
 def loads(e, u):
-    if ABLATE == "dma":
+    if DMA:
         for ff in range(2):
             k = 2 * u + ff
             e("v_readfirstlane_b32 s%d, v%d", ST3, DMA_BASE + k)     # (not ST0/ST1: the prologue keeps the taps pointer there)
@@ -435,12 +437,12 @@ def unit(e, ui, nuw, packed=True):
             e.place(skip)
         else:
             loads(e, nx)
-    if ABLATE != "dma":
+    if not DMA:
         next_loads()
     stamp(e, 1)
     # ---- filter, gain
     filter_stream(e, packed)
-    if ABLATE == "dma":
+    if DMA:
         next_loads()
     for i in range(4):
         e("v_cvt_f64_f32 %s, v%d", vp(P0 + 2 * i), ACC + i)
@@ -510,7 +512,7 @@ def block(nuw, packed=True):
     e("v_readfirstlane_b32 s%d, v%d", SIX, PRE + 13)
     e("v_readfirstlane_b32 s%d, v%d", ST0, PRE + 16)
     e("v_readfirstlane_b32 s%d, v%d", ST1, PRE + 17)
-    if ABLATE == "dma":         # per-lane DMA source offsets and the DMA regions' LDS addresses: a table the kernel left in the (still unused) window
+    if DMA:         # per-lane DMA source offsets and the DMA regions' LDS addresses: a table the kernel left in the (still unused) window
         e("v_mov_b32_e32 v%d, m0", DMA_M0)
         for k in range(2 * nuw):
             for j in range(4):
@@ -548,7 +550,7 @@ def block(nuw, packed=True):
     e.place("Lexit_%=")
     e("s_setprio 0")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    if ABLATE == "dma":
+    if DMA:
         e("v_readfirstlane_b32 s%d, v%d", ST0, DMA_M0)
         e("s_mov_b32 m0, s%d", ST0)
     if PROFILE and not ABLATE:
@@ -563,7 +565,7 @@ def emit_function(nuw, packed=True):
     ops = ['[prm] "v"(prm_addr)', '[rd] "v"(rd_addr)', '[voff] "v"(voff)', '[symoff] "v"(symoff)', '[smem] "v"(smem_addr)',
            '[wlim] "v"(w.wlim)', '[wpad] "v"(w.wpad)']
     args = ["unsigned prm_addr", "unsigned rd_addr", "unsigned voff", "unsigned symoff", "unsigned smem_addr"]
-    if ABLATE == "dma":
+    if DMA:
         ops.append('[tab] "v"(tab_addr)')
         args.append("unsigned tab_addr")
     for ui in range(nuw):
@@ -589,7 +591,7 @@ __device__ __forceinline__ int fir_lean_loop%(nuw)d%(sfx)s(%(args)s, const LeanL
 }
 ''' % dict(nuw=nuw, n=len([ln for ln in lines if not ln.endswith(":")]), nvalu=nvalu, args=", ".join(args), body=body,
            ops=",\n          ".join(ops), clob=", ".join(clob), outs=",\n          ".join(outs),
-           sfx=("" if packed else "u") + ("_a" + ABLATE if ABLATE else "_prof" if PROFILE else ""),
+           sfx=("" if packed else "u") + ("_dma" if DMA else "") + ("_a" + ABLATE if ABLATE else "_prof" if PROFILE else ""),
            how="" if packed else ", the filter in single-float instructions (the wave beside the serial wave)", parg=", unsigned (&prof)[%d]" % NPROF if stamped else "")
 
 
@@ -610,7 +612,7 @@ constexpr int FIR_LEAN_NPROF = %d;
     print(emit_function(1))
     print(emit_function(2))
     global ABLATE
-    for ABLATE in ("valu", "lds", "flush", "stage", "store", "ring", "order", "dma"):
+    for ABLATE in ("valu", "lds", "flush", "stage", "store", "ring", "order"):
         print(emit_function(1))
         print(emit_function(2))
     ABLATE = None
@@ -659,6 +661,21 @@ struct LeanLaneAddr {
 ''' % dict(v0=PRE, v1=VLAST, s0=SRC, s1=TAP0 + 63, t0=TAP0, ws=WS_SLOTS))
     print(emit_function(1))
     print(emit_function(2))
+    global DMA
+    DMA = True
+    print("""/*
+ * The same loops with the window staged by LDS-DMA (round 5): of a frame's 512 new samples per chunk, the first 384 go from memory
+ * straight into the window -- four global_load_lds_dwordx4 per frame, issued as soon as the unit before has filtered (the wave's
+ * window is then free; the other waves of the SIMD cover the latency), each lane's SOURCE offset chosen so that the lane-linear
+ * destination is the padded window image; the last 128, which are also the next chunk's history, keep the register path.  Per
+ * frame and chunk: 4 DMAs + 1 load + 2 ds_write_b128 instead of 4 loads + 5 ds_write_b128, 21 instead of 32 staging registers.
+ * Extra contract: every decimation offset of the wave's frames is EVEN (the DMA moves 16-byte pairs); tab_addr = LDS byte address
+ * of the lane's column in a table the kernel leaves at the start of the wave's (still unused) window: dwords [4 k + j][64] = byte
+ * offset of lane l's pair in DMA j of frame k = 2 unit + frame, [16 + k][64] = LDS byte address of the frame's DMA region.
+ */""")
+    print(emit_function(1))
+    print(emit_function(2))
+    DMA = False
     print("} // namespace qpsk\n#endif")
 
 
