@@ -474,6 +474,29 @@ def main():
                 ent["parity_frames_checked"] = npar_t
                 ent["symbol_mismatches"] = int(np.sum(outs_t[0][:npar_t].cpu().numpy() != want_t["sym"]))
                 ent["index_mismatches"] = int(np.sum(idx_t[:npar_t].cpu().numpy() != want_t["index"]))
+            if key == "hist":
+                # VERDICT r4 item 6, "histogram mode in one pass": the route that reads the batch ONCE -- full-rate filter + scan with the
+                # filtered block written planar by decimation phase, then the loop kernel on the one plane the index picks (no second read
+                # of the input, no decimating filter) -- exists as the streams' kernels (stream_scan_kernel MODE 0 + costas_pipe_kernel);
+                # the same batch as 4096 one-block streams, steady state of blocks 2..5 (same kernels, same bytes per block; a stream's
+                # loop runs a block behind, qpsk.c:186-197, so the symbols are not the batch's: the streams have their own gate below)
+                mo = qpsk_amd.Modem(fs=FS, rs=RS, frame_size=L, timing_mode=qpsk_amd.TIMING_HIST, device=local)
+                mo.streams_reset(F, 0.0)
+                to = []
+                for k_ in range(6):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    mo.streams_rx_cplx(x, want_costas=False)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    to.append(e0.elapsed_time(e1))
+                mo.sync()
+                ent["one_pass_route"] = {
+                    "kernels": mo.last_kernel(), "ms_per_block": float(np.median(to[2:])),
+                    "what": "filter + scan once, the filtered block written planar by decimation phase (512 MiB written), loop kernel on the picked plane",
+                    "against": "ms_per_step of this key: the input read twice (timing_scan_kernel, then the fused receive kernel's decimating filter)",
+                    "faster": bool(float(np.median(to[2:])) < dtt / steps_ * 1e3)}
+                mo.close()
             res[key] = ent
             mt.close()
             del outs_t, idx_t
