@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Copy the outputs of tools/measure_r04.sh from gpurun_out/r04/ (scratch) into profiles/r04_* (tracked) and rebuild
-profiles/traffic.json from the HBM counter passes.  No narrative is added here: every file says which command produced it.
+"""Copy the outputs of tools/measure_r04.sh (or measure_r05.sh) from gpurun_out/<tag>/ (scratch) into profiles/<tag>_* (tracked) and
+rebuild profiles/traffic.json from the HBM counter passes.  No narrative is added here: every file says which command produced it.
 
-    python tools/collect_r04.py
+    python tools/collect_r04.py [tag]        (default r04; `r05` reads gpurun_out/r05 and writes profiles/r05_*)
+
+traffic.json carries the sha256 of the library the counters were taken on (gpurun_out/<tag>/library.sha256, written by the
+measurement script): bench.py compares it with the library it runs and says `traffic_matches_library`.
 
 PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md: counters in their own passes; FETCH_SIZE and WRITE_SIZE are in KiB;
 on gfx950 FETCH_SIZE counts a 128-byte request of a 16-byte-per-lane streaming read as 64 bytes, hence the factor 2 on reads.
@@ -13,11 +16,12 @@ import glob
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r04")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+SRC = os.path.join(ROOT, "gpurun_out", TAG)
 OUT = os.path.join(ROOT, "profiles")
-TAG = "r04"
 
 
 def ok(name):
@@ -70,7 +74,8 @@ def median(v):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    for n in ("bench", "bench20", "bench8192", "bench_gpus2_shared", "bench_gpus6_shared", "bench_torchrun2_shared", "bench_torchrun4_shared"):
+    for n in ("bench", "bench20", "bench8192", "bench_gpus2_shared", "bench_gpus6_shared", "bench_torchrun2_shared", "bench_torchrun4_shared",
+              "bench_gpus2_shared_20steps", "bench_gpus6_shared_20steps"):
         p = os.path.join(SRC, n + ".json")
         if ok(n) and os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(OUT, "%s_%s.json" % (TAG, n)))
@@ -104,6 +109,13 @@ def main():
         open(os.path.join(OUT, "%s_hbm_traffic.txt" % TAG), "w").write("\n".join(lines) + "\n")
         print("\n".join(lines[4:]))
     if shapes:
+        sha = None
+        try:
+            sha = open(os.path.join(SRC, "library.sha256")).read().split()[0]
+        except OSError:
+            pass
+        for v in shapes.values():
+            v["library_sha256"] = sha
         tj = dict(shapes.get("4096x16384", {}))
         tj["shapes"] = shapes
         json.dump(tj, open(os.path.join(OUT, "traffic.json"), "w"), indent=1)
