@@ -458,6 +458,38 @@ def test_full_size_config4_shard_properties(oracle):
     assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0)
 
 
+def test_config4_whole_job_shard_after_shard(oracle):
+    """BASELINE config 4 AS A JOB: 65,536 frames x 16,384 samples sharded over 8 ranks (qpsk_amd.shard.shard_range, the ranges and seeds
+    bench.py's ranks use).  There is one GPU here, so the eight shards run one after the other on it: every frame of the job goes
+    through rx_lean_kernel, every loop must end on the +50 Hz offset, the shards must tile the job exactly, and a spread sample of
+    every shard equals the oracle bit for bit.  (The eight-GPU run is the driver's; this is the same work, serially.)"""
+    import torch
+    import bench
+    import qpsk_amd
+    from qpsk_amd.shard import shard_range
+    fs, rs, L, TOTAL, WORLD = bench.FS, bench.RS, 16384, 65536, 8
+    dev = torch.device("cuda", 0)
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=bench.FIXED_INDEX)
+    covered, hashes = 0, set()
+    for rank in range(WORLD):
+        lo, hi = shard_range(TOTAL, rank, WORLD)
+        assert lo == covered and hi - lo == bench.FRAMES_PER_GPU_SHARDED
+        covered = hi
+        x = bench.tx_frames_gpu(torch, dev, qpsk_amd, hi - lo, seed=1000 + rank)
+        a = m.rx_batch(x)
+        m.sync()
+        assert m.last_kernel() == "rx_lean_kernel"
+        assert np.all(np.abs(cpu(a["hz"]) - 50.0) < 2.0), rank
+        pick = np.unique(np.concatenate([np.arange(rank, hi - lo, 521), [0, 31, 32, hi - lo - 1]]))
+        want = oracle.rx_batch(x[torch.from_numpy(pick).cuda()].cpu().numpy(), fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED,
+                               fixed_index=bench.FIXED_INDEX)
+        for k in ("sym", "phase", "freq", "hz"):
+            assert bits_equal(cpu(a[k])[pick], want[k]), (rank, k)
+        hashes.add(hash(cpu(a["sym"])[:4].tobytes()))
+        del x, a
+    assert covered == TOTAL and len(hashes) == WORLD        # eight different shards (different seeds), the whole job
+
+
 @pytest.mark.parametrize("mode", [TIMING_FIXED, TIMING_HIST])
 def test_smallest_frames(oracle, mode):
     """frames of one symbol up to just over one chunk, one to three frames per call, both pipeline geometries:
