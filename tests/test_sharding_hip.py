@@ -121,7 +121,10 @@ def test_two_rank_clock_excludes_the_rendezvous():
     """The N > 1 clock stops when a rank's K steps are done, in front of the trailing barrier (round 4 timed the gloo rendezvous:
     0.76 ms per region = 13 % of the driver's 20-step region).  Two ranks at the real per-GPU shape (8192 x 16384 each, sharing the
     one GPU of this box), --steps 20 like the driver: the job's wall time per step must be the kernels' time -- rank 0's event span
-    over its K launches, which on a shared GPU contains the other rank's launches too -- within 2 %."""
+    over its K launches, which on a shared GPU contains the other rank's launches too.  Tolerance 4 %: the two ranks' launches
+    alternate on the one GPU, so ONE launch of the other rank (1/40 of the region = 2.5 %) falls inside one rank's clock and
+    outside the other's event span -- a granularity of the rehearsal that eight GPUs do not have (measured: 0.7-2.8 %,
+    profiles/r05_bench_gpus2_shared_20steps.json, ..._gpus6_...); the rendezvous round 4 timed was 7.5 % of this region."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -130,7 +133,7 @@ def test_two_rank_clock_excludes_the_rendezvous():
     assert d["ranks"] == 2 and d["steps"] == 20 and d["config"]["frames_per_gpu"] == 8192
     assert d["parity"]["symbol_mismatches"] == 0 and d["parity"]["hz_out_of_range"] == 0
     wall, kern = d["ms_per_step"], d["roofline"]["kernel_ms"]
-    assert abs(wall - kern) < 0.02 * kern, (wall, kern)
+    assert abs(wall - kern) < 0.04 * kern, (wall, kern)
 
 
 def test_bench_gpus_flag_is_not_ignored():
