@@ -599,9 +599,9 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     /* ---- which kernel takes the batch: decided ONCE, here, as a plan; the timing estimate's placement (below) reads the plan and
      * the launches execute it -- nothing restates the choice (round 4 restated it for the in-launch FFT estimate and missed a
      * tuning key: QPSK_PIPE_G above 16 sent the batch to rx_lean_kernel with no index computed).
-     * Two pipeline kernels [measured, DESIGN.md 4.1]: up to 16 frames per CU the recurrence is the limit and the 16-frame workgroups
-     * of rx_fused_pipe_kernel (serial wave alone on its SIMD, four-symbol FIR lanes) are ahead; above that the filter is the limit
-     * and the 32-frame workgroups of rx_lean_kernel / rx_pipe2_kernel win by 20 %. */
+     * The pipeline kernels [measured, DESIGN.md 4.1]: rx_lean_kernel wherever its stream serves the shape in one launch (see below);
+     * rx_fused_pipe_kernel (16-frame workgroups, four-symbol FIR lanes, the FFT timing estimate inside the launch) for ragged batches
+     * up to 16 frames per CU, several loops per frame, a costas_frame[] dump and config 3; rx_pipe2_kernel for those above 16. */
     enum { K_GENERIC, K_FUSED_PIPE, K_PIPE2, K_LEAN };
     struct Plan {
         int kind = K_GENERIC, nframes = 0, G = 0, nf = 0;
@@ -674,7 +674,14 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
         G = tuned(c->tune.pipe_g, G);
         if (G > pipe2_max_frames()) G = pipe2_max_frames();
         G += G & 1;
-        const bool wanted = pipe_v == 3 || G > 16;      /* up to 16 frames per CU the serial wave decides: rx_fused_pipe_kernel */
+        /* above 16 frames per CU: always (the filter is the limit there).  Up to 16 frames per CU both kernels sit on the serial wave,
+         * and since round 5 (LDS-DMA staging, two-unit FIR waves) this one is ahead there too -- 0.1546 against 0.1575 ms at config 2,
+         * 1-2 % at 1024-3584 frames (profiles/r05_config2_lean.txt) -- for batches it takes in ONE launch (whole workgroups of at least
+         * four frames).  The FFT timing estimate inside the launch exists only in rx_fused_pipe_kernel: config 3's shape stays there. */
+        const bool fft_inline = c->prm.timing_mode == QPSK_TIMING_FFT && tuned(c->tune.fft_fused, 1) != 0 &&
+                                (long long)nframes > (long long)c->ncu * pipe_frames(pipe_max_nf() - 1) &&
+                                c->prm.frame_size >= timing_fft_first() + timing_fft_nfft();
+        const bool wanted = pipe_v == 3 || G > 16 || (G >= 4 && nframes % G == 0 && !fft_inline);
         unsigned long long layout = 0;
         if (c->tune.layout_lo >= 0 || c->tune.layout_hi >= 0)
             layout = ((unsigned long long)(unsigned)tuned(c->tune.layout_lo, 0) << 4) |

@@ -1685,6 +1685,16 @@ size_t lean_lds_bytes(int G, int nwin)
  */
 unsigned long long lean_default_layout(int NU)
 {
+    if (NU == 8) {
+        /* 16 frames per workgroup (BASELINE config 2): the serial wave alone on SIMD 0; 3, 3, 2 units on SIMDs 1-3 as two-unit
+         * waves 1, 2, 3 and one-unit waves 5, 6 -- five FIR waves, not eight: a two-unit wave covers the LDS-DMA latency of one unit
+         * with the filter of the other.  [measured, profiles/r05_config2_lean.txt, one process: 0.1532 ms against 0.1578 with eight
+         * one-unit waves and 0.1621 for rx_fused_pipe_kernel; a unit beside the serial wave: 0.1797] */
+        static const int c8[12] = {0, 2, 2, 2, 0, 1, 1, 0, 0, 0, 0, 0};
+        unsigned long long l8 = 0;
+        for (int w = 1; w < 12; w++) l8 |= (unsigned long long)c8[w] << (4 * w);
+        return l8;
+    }
     if (NU != pipe2::MAX_UNITS) return pipe2_default_layout(NU);
     static const int cnt[12] = {0, 2, 2, 2, 1, 2, 2, 2, 0, 1, 1, 1};
     unsigned long long layout = 0;

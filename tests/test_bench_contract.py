@@ -54,7 +54,7 @@ def test_bench_json_line():
     assert rl["algorithmic_bytes_per_launch"] == 8 * 256 * d["config"]["frame_size"]
     # provenance: the kernel name comes from the library, the traffic constant names its source (none for this shape),
     # the library file that was actually loaded is identified by path and hash
-    assert rl["kernel"] in ("rx_fused_pipe_kernel", "rx_pipe2_kernel", "rx_fused_kernel") and "traffic_source" in rl
+    assert rl["kernel"] in ("rx_lean_kernel", "rx_fused_pipe_kernel", "rx_pipe2_kernel", "rx_fused_kernel") and "traffic_source" in rl
     assert rl["traffic"] is None and rl["traffic_source"] is None
     import hashlib
     lib = d["library"]

@@ -121,7 +121,7 @@ def test_rx_batch_fft_timing(oracle, fs, rs, L, F):
 @pytest.mark.parametrize("tune,kernel", [(dict(pipe_g=32), "rx_lean_kernel"), (dict(pipe_g=20), "rx_lean_kernel"),
                                          (dict(pipe_v=2), "rx_pipe2_kernel"), (dict(pipe_v=3), "rx_lean_kernel"),
                                          (dict(pipe_nf=2), "rx_fused_pipe_kernel"), (dict(fused_generic=1), "rx_fused_kernel"),
-                                         (dict(fft_fused=0), "rx_fused_pipe_kernel"), (dict(pipe_dbg=128), "rx_fused_pipe_kernel"),
+                                         (dict(fft_fused=0), "rx_lean_kernel"), (dict(pipe_dbg=128), "rx_fused_pipe_kernel"),
                                          (dict(), "rx_fused_pipe_kernel (FFT timing estimate inside the launch)")])
 def test_fft_timing_under_every_geometry_key(oracle, tune, kernel):
     """No tuning key may change a result (include/qpsk_hip.h).  Round 4's host code restated the kernel choice to decide whether the
@@ -393,7 +393,7 @@ def test_full_size_config2_bench_stimulus_every_frame(oracle):
     x = bench.tx_frames_gpu(torch, dev, qpsk_amd, F, seed=1000)
     a = m.rx_batch(x)
     m.sync()
-    assert m.last_kernel() == "rx_fused_pipe_kernel"
+    assert m.last_kernel() == "rx_lean_kernel"          # config 2's kernel since round 5 (16-frame workgroups, LDS-DMA staging)
     want = oracle.rx_batch(x.cpu().numpy(), fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=bench.FIXED_INDEX,
                            threads=min(16, os.cpu_count() or 1))
     for k in ("sym", "phase", "freq", "hz"):
