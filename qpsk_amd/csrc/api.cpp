@@ -583,6 +583,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     a.fixed_index = c->prm.fixed_index;
     a.dbg = tuned(c->tune.pipe_variant, 0) & PIPE_VARIANT_MASK;
     a.lean_dma = tuned(c->tune.lean_dma, 1) != 0;
+    a.lean_twowin = tuned(c->tune.lean_dma, 1) != 2 ? 1 : 0;      /* QPSK_LEAN_DMA = 2: LDS-DMA, but one window per FIR wave whatever the LDS allows */
     a.taps = c->d_taps;
     a.gains = c->d_gains;
     a.nbw = nbw;

@@ -34,6 +34,8 @@ struct FusedArgs {
      * candidate phases (both host-built, api.cpp); index_out [nframes] or NULL receives the indices.  NULL = off */
     const double2 *est_tw, *est_cs;
     int32_t *index_out;
+    int lean_twowin;        /* rx_lean_kernel, set by launch_rx_lean when the LDS allows it (workgroups of up to 16 frames): every two-frame unit has
+                               a window of its own, so a two-unit FIR wave's DMAs run a whole unit ahead (fir_lean_loop2_dma2w) */
     int lean_dma;           /* rx_lean_kernel: 1 = FIR waves whose frames all have an even decimation offset stage their windows by LDS-DMA
                                (fir_lean_asm.h, the _dma loops); 0 = always through registers.  Same bits either way ("QPSK_LEAN_DMA") */
     int dbg;                /* layout variants of the pipeline kernel, all bit-exact (qpsk_ctx_set_tuning "QPSK_PIPE_DBG"):

@@ -1486,6 +1486,7 @@ static_assert(sizeof(Ctl) % 16 == 0 && offsetof(Ctl, ready) == 0 && offsetof(Ctl
               offsetof(Ctl, abort_flag) == 68, "fir_lean_asm.h addresses the counters by these offsets");
 static_assert(PRM_DWORDS * 4 <= ROW_BYTES - Z_OFFSET_BYTES, "a parameter block fits the record half of a row");
 static_assert(FIR_LEAN_END_VGPR <= 168, "three waves per SIMD");
+static_assert(FIR_LEAN_WOFF == sizeof(float2) * pipe2::UF * WS, "fir_lean_loop2_dma2w: unit 1's window follows unit 0's");
 static_assert(WS % 2 == 0 && pipe2::slot_of(pipe2::PAD * (pipe2::QL - 1) + pipe2::TSTEPS - 1) < WS &&
               pipe2::slot_of(pipe2::CH + HIST - 1) < WS + 16, "window: every position a lane reads, and a frame's spill stays in the next frame's history slots");
 __device__ __host__ constexpr int rows_of(int G) { return G > HW_WAVES ? G : HW_WAVES; }
@@ -1515,8 +1516,9 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
             const int ix = __builtin_amdgcn_readfirstlane(a.index ? a.index[fr] : a.fixed_index) & 7;   /* decimation offset, < C */
             if (ui < NUW) ixpack |= (unsigned)ix << (4 * (2 * ui + ff));
             const int p0 = 2 * lane + HIST - ix;          /* window position of sample 2*lane of a chunk */
-            w.wr0[ui][ff] = lds_addr(mywin + ff * WS + slot_of(p0)) - 8u * BLK;
-            w.wr1[ui][ff] = lds_addr(mywin + ff * WS + slot_of(p0 + 1)) - 8u * BLK;
+            const int wu = (NUW == 2 && a.lean_twowin && ui == 1) ? UF * WS : 0;      /* unit 1's own window, FIR_LEAN_WOFF bytes up */
+            w.wr0[ui][ff] = lds_addr(mywin + wu + ff * WS + slot_of(p0)) - 8u * BLK;
+            w.wr1[ui][ff] = lds_addr(mywin + wu + ff * WS + slot_of(p0 + 1)) - 8u * BLK;
             if (lane == 0) {
                 size_t fsrc = (size_t)fr;
 #ifdef QPSK_PIPE_PROFILE
@@ -1604,11 +1606,14 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
                     if (n > CH - 2) n = CH - 2;          /* lanes the last DMA masks off */
                     tab[(4 * k + j) * 64 + lane] = 8u * (unsigned)n;
                 }
-                tab[(16 + k) * 64 + lane] = lds_addr(mywin + ff * WS + S0);
+                tab[(16 + k) * 64 + lane] = lds_addr(mywin + ((NUW == 2 && a.lean_twowin && ui == 1) ? UF * WS : 0) + ff * WS + S0);
             }
-        if constexpr (NUW == 2)
-            st = fir_lean_loop2_dma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
-        else
+        if constexpr (NUW == 2) {
+            if (a.lean_twowin)
+                st = fir_lean_loop2_dma2w(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
+            else
+                st = fir_lean_loop2_dma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
+        } else
             st = fir_lean_loop1_dma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
     } else if constexpr (NUW == 2)
         st = fir_lean_loop2(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), w);
@@ -1661,7 +1666,7 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
     for (int v = 1; v < wave; v++) {
         const int cv = (int)((layout >> (4 * v)) & 15);
         u0 += cv;
-        widx += cv != 0;
+        widx += a.lean_twowin ? cv : (cv != 0);      /* a window per unit, or one per FIR wave */
     }
     float2 *mywin = win + (size_t)widx * UF * lean::WS;
     if (mine == 2)
@@ -1728,6 +1733,9 @@ int launch_rx_lean(const FusedArgs &a0, int G, unsigned long long layout, int *s
     a.G = G;
     a.mixed = 2;
     a.share_simd0 = ((layout >> 16) & 15) != 0 || ((layout >> 32) & 15) != 0;
+    /* a window per UNIT where the LDS has the room (up to 16 frames per workgroup; a.lean_twowin comes in as the caller's wish) */
+    a.lean_twowin = a.lean_twowin && a.lean_dma && units > nwin && lean_lds_bytes(G, units) <= (size_t)MAX_LDS_BYTES;
+    if (a.lean_twowin) nwin = units;
     hipLaunchKernelGGL(rx_lean_kernel, dim3(a.nframes / G), dim3(64 * hw), lean_lds_bytes(G, nwin), s, a, layout, nwin, status);
     return (int)hipGetLastError();
 }

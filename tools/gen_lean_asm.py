@@ -74,6 +74,11 @@ PROFILE = False
 #            granules).  [measured, profiles/r05_energy_ledger.txt] bit-exact, 1.7 % less energy per launch at 8192 frames.
 ABLATE = None
 DMA = False          # the stream with LDS-DMA window staging (fir_lean_loop*_dma), see "dma" above: product code since round 5
+TWOWIN = False       # DMA stream of a two-unit wave that has a window PER UNIT (fir_lean_loop2_dma2w; workgroups of up to 16 frames leave the
+                     # LDS for it): unit 1's window lies WOFF bytes above unit 0's, so the next unit's DMAs are issued a whole unit ahead again
+                     # (their window is not being read) and both units' first chunks are in flight from the start
+WOFF = 2 * WS_SLOTS * 8          # bytes of one unit's window (two frames)
+DMA_WLIM1, DMA_WPAD1 = 57, 58    # v57, v58: wlim / wpad of unit 1's window (TWOWIN)
 # registers of the DMA stream (the prefetch registers v32..v63 are free there except the block-3 quads v44..47 / v60..63):
 DMA_OFF = [32, 36, 40, 48]      # per (unit, frame) k = 2 ui + ff: four per-lane source byte offsets, one per DMA
 DMA_BASE = 52                   # v52..v55: LDS byte address of the DMA region of frame k (wave-uniform)
@@ -152,18 +157,18 @@ def wreg(t):
     return vp(wreg_base(t))
 
 
-def fetch(e, b):
+def fetch(e, b, woff=0):
     n = 0
     for u in range(0, C, 2):
         t = b * C + u
         if t < TSTEPS:
             r = W0 + 16 * (b % NW) + 2 * u
-            e("ds_read_b128 %s, %%[rd] offset:%d", v4(r), 8 * slot_of(t))
+            e("ds_read_b128 %s, %%[rd] offset:%d", v4(r), 8 * slot_of(t) + woff)
             n += 1
     return n
 
 
-def filter_stream(e, packed=True):
+def filter_stream(e, packed=True, woff=0):
     """the sum of fir_r2_asm.h (tools/gen_fir_asm.py) with the taps as SGPR operands.  packed=False (not emitted; kept for
     the record): the same products and sums as single-float instructions, re and im apart -- tried for the FIR wave beside
     the serial wave on the idea that a single-float instruction holds the SIMD for 2 cycles; it holds it for 4 like a packed
@@ -171,7 +176,7 @@ def filter_stream(e, packed=True):
     reads = {}
     nolds = ABLATE == "lds"
     for d in range(min(DEPTH, NB)):
-        reads[d] = fetch(e, d)
+        reads[d] = fetch(e, d, woff)
     if ABLATE == "valu":        # a plausible symbol instead of the sum (a zero would send the loop to its exact-zero path)
         for i in range(2):
             e("v_mov_b32_e32 v%d, 0x3f333333", ACC + 2 * i)
@@ -183,7 +188,7 @@ def filter_stream(e, packed=True):
     nmul = 0
     for b in range(NB):
         if b + DEPTH < NB:
-            reads[b + DEPTH] = fetch(e, b + DEPTH) if not (nolds and b + DEPTH >= NW) else 0
+            reads[b + DEPTH] = fetch(e, b + DEPTH, woff) if not (nolds and b + DEPTH >= NW) else 0
         later = sum(reads.get(x, 0) for x in range(b + 1, min(NB, b + DEPTH + 1)))
         e("s_waitcnt lgkmcnt(%d)", later)
         for u in range(0, C, 2):
@@ -238,10 +243,12 @@ def stage_frame(e, ui, ff):
     # The window keeps positions 0..633 (WS_SLOTS slots; no lane reads past 630): the last samples of a chunk, which matter only
     # as the NEXT chunk's history (registers), would land past it.  Frame 0's spill into the first slots of frame 1 -- staged
     # after it, in order -- is harmless; frame 1's would hit the next wave's window, so those lanes write a pad slot instead.
+    wlim, wpad = ("v%d" % DMA_WLIM1, "v%d" % DMA_WPAD1) if (TWOWIN and ui == 1) else ("%[wlim]", "%[wpad]")
+
     def clamped(dst, base):
         e("v_add_u32_e32 v%d, 0x%x, %s", dst, 4 * BLK_BYTES, base)
-        e("v_cmp_gt_u32_e32 vcc, v%d, %%[wlim]", dst)
-        e("v_cndmask_b32_e32 v%d, v%d, %%[wpad], vcc", dst, dst)
+        e("v_cmp_gt_u32_e32 vcc, v%d, %s", dst, wlim)
+        e("v_cndmask_b32_e32 v%d, v%d, %s, vcc", dst, dst, wpad)
     for j in ((3,) if DMA else range(4)):
         if ff == 1 and j == 3:
             clamped(P0, wr0)
@@ -437,12 +444,12 @@ def unit(e, ui, nuw, packed=True):
             e.place(skip)
         else:
             loads(e, nx)
-    if not DMA:
+    if not DMA or TWOWIN:
         next_loads()
     stamp(e, 1)
     # ---- filter, gain
-    filter_stream(e, packed)
-    if DMA:
+    filter_stream(e, packed, WOFF if (TWOWIN and ui == 1) else 0)
+    if DMA and not TWOWIN:
         next_loads()
     for i in range(4):
         e("v_cvt_f64_f32 %s, v%d", vp(P0 + 2 * i), ACC + i)
@@ -519,6 +526,9 @@ def block(nuw, packed=True):
                 e("ds_read_b32 v%d, %%[tab] offset:%d", DMA_OFF[k] + j, 256 * (4 * k + j))
             e("ds_read_b32 v%d, %%[tab] offset:%d", DMA_BASE + k, 256 * (16 + k))
         e("s_waitcnt lgkmcnt(0)")
+        if TWOWIN:
+            e("v_add_u32_e32 v%d, 0x%x, %%[wlim]", DMA_WLIM1, WOFF)
+            e("v_add_u32_e32 v%d, 0x%x, %%[wpad]", DMA_WPAD1, WOFF)
     loads(e, 0)                 # the first unit's samples at once: their HBM latency covers the tap loads and the set-up below
     for i in range(4):
         e("s_load_dwordx16 s[%d:%d], %s, 0x%x", TAP0 + 16 * i, TAP0 + 16 * i + 15, sp(ST0), 64 * i)
@@ -591,7 +601,7 @@ __device__ __forceinline__ int fir_lean_loop%(nuw)d%(sfx)s(%(args)s, const LeanL
 }
 ''' % dict(nuw=nuw, n=len([ln for ln in lines if not ln.endswith(":")]), nvalu=nvalu, args=", ".join(args), body=body,
            ops=",\n          ".join(ops), clob=", ".join(clob), outs=",\n          ".join(outs),
-           sfx=("" if packed else "u") + ("_dma" if DMA else "") + ("_a" + ABLATE if ABLATE else "_prof" if PROFILE else ""),
+           sfx=("" if packed else "u") + ("_dma" if DMA else "") + ("2w" if TWOWIN else "") + ("_a" + ABLATE if ABLATE else "_prof" if PROFILE else ""),
            how="" if packed else ", the filter in single-float instructions (the wave beside the serial wave)", parg=", unsigned (&prof)[%d]" % NPROF if stamped else "")
 
 
@@ -675,7 +685,17 @@ struct LeanLaneAddr {
  */""")
     print(emit_function(1))
     print(emit_function(2))
+    global TWOWIN
+    TWOWIN = True
+    print("""/*
+ * fir_lean_loop2_dma with a window PER UNIT (workgroups of up to 16 frames leave the LDS for it; the kernel puts unit 1's window
+ * %d bytes above unit 0's, and w.wr0 / w.wr1 / the DMA table of unit 1 point there): a unit's DMAs no longer wait for the other
+ * unit's filter -- they are issued a whole unit ahead, and both units' first chunks are in flight from the first instruction.
+ */""" % WOFF)
+    print(emit_function(2))
+    TWOWIN = False
     DMA = False
+    print("constexpr unsigned FIR_LEAN_WOFF = %d;" % WOFF)
     print("} // namespace qpsk\n#endif")
 
 
