@@ -1506,6 +1506,18 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
     const bool simd0 = (hwave & 3) == 0;                 /* placed beside the serial wave (layout): keeps priority 3 */
     unsigned *prm = reinterpret_cast<unsigned *>(rows + (size_t)hwave * lean::ROW_BYTES + lean::Z_OFFSET_BYTES);
     unsigned ixpack = ((unsigned)(4 * u0) << 16) | (simd0 && !(a.dbg & 1024) ? 0x80000000u : 0u);
+#pragma unroll
+    for (int ui = 0; ui < NUW; ui++)
+#pragma unroll
+        for (int ff = 0; ff < UF; ff++) {
+            const int fr = f0 + UF * (u0 + ui) + ff;
+            const int ix = __builtin_amdgcn_readfirstlane(a.index ? a.index[fr] : a.fixed_index) & 7;   /* decimation offset, < C */
+            ixpack |= (unsigned)ix << (4 * (2 * ui + ff));
+        }
+    /* which stream this wave runs (wave-uniform): LDS-DMA staging needs even offsets (16-byte pairs); a two-unit wave that stages by
+     * DMA uses the window per unit the launch has set aside (lean_twowin), every other wave the first of its windows only */
+    const bool use_dma = a.lean_dma && (ixpack & 0x1111u) == 0;
+    const bool two_windows = NUW == 2 && a.lean_twowin && use_dma;
     LeanLaneAddr w;
 #pragma unroll
     for (int ui = 0; ui < 2; ui++) {
@@ -1513,10 +1525,9 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
 #pragma unroll
         for (int ff = 0; ff < UF; ff++) {
             const int fr = f0 + UF * u + ff;
-            const int ix = __builtin_amdgcn_readfirstlane(a.index ? a.index[fr] : a.fixed_index) & 7;   /* decimation offset, < C */
-            if (ui < NUW) ixpack |= (unsigned)ix << (4 * (2 * ui + ff));
+            const int ix = (int)((ixpack >> (4 * (2 * (ui < NUW ? ui : 0) + ff))) & 7u);
             const int p0 = 2 * lane + HIST - ix;          /* window position of sample 2*lane of a chunk */
-            const int wu = (NUW == 2 && a.lean_twowin && ui == 1) ? UF * WS : 0;      /* unit 1's own window, FIR_LEAN_WOFF bytes up */
+            const int wu = (two_windows && ui == 1) ? UF * WS : 0;      /* unit 1's own window, FIR_LEAN_WOFF bytes up */
             w.wr0[ui][ff] = lds_addr(mywin + wu + ff * WS + slot_of(p0)) - 8u * BLK;
             w.wr1[ui][ff] = lds_addr(mywin + wu + ff * WS + slot_of(p0 + 1)) - 8u * BLK;
             if (lane == 0) {
@@ -1583,7 +1594,7 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
 #undef QPSK_LEAN_ABLATED
     } else
 #endif
-    if (a.lean_dma && (ixpack & 0x1111u) == 0) {
+    if (use_dma) {
         /* Window staging by LDS-DMA (fir_lean_asm.h, the _dma loops): every decimation offset of the wave's frames is even, so the
          * 16-byte pairs of the window image are 16-byte pairs of the input.  The table the stream reads first, left in the still
          * unused window: per frame k = 2 unit + frame the four per-lane source byte offsets of its DMAs -- DMA j's lane l fills
@@ -1606,10 +1617,10 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
                     if (n > CH - 2) n = CH - 2;          /* lanes the last DMA masks off */
                     tab[(4 * k + j) * 64 + lane] = 8u * (unsigned)n;
                 }
-                tab[(16 + k) * 64 + lane] = lds_addr(mywin + ((NUW == 2 && a.lean_twowin && ui == 1) ? UF * WS : 0) + ff * WS + S0);
+                tab[(16 + k) * 64 + lane] = lds_addr(mywin + ((two_windows && ui == 1) ? UF * WS : 0) + ff * WS + S0);
             }
         if constexpr (NUW == 2) {
-            if (a.lean_twowin)
+            if (two_windows)
                 st = fir_lean_loop2_dma2w(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
             else
                 st = fir_lean_loop2_dma(lds_addr(prm), rd, 16u * lane, (unsigned)(fl * N + R * q), lds_addr(sm), lds_addr(tab + lane), w);
