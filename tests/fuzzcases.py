@@ -70,6 +70,15 @@ def batch_case(oracle, modem_factory, seed, max_samples=6_000_000):
     nsym = int(_pick(rng, [128, 128, 192, 256, 100, 37])) if big else _nsym(rng)
     L = nsym * cycles
     F = int(rng.integers(4097, 9000)) if big else int(_pick(rng, [rng.integers(1, 6), rng.integers(6, 80), rng.integers(80, 700)]))
+    if not big and rng.integers(0, 7) == 0:
+        # 4..16 frames per CU in whole workgroups: the shapes rx_lean_kernel takes in one launch since round 5 (16-frame workgroups,
+        # LDS-DMA staging with a window per unit when every timing offset of a wave is even, registers otherwise)
+        fs, rs, cycles = 19200.0, 2400.0, 8
+        taps = oracle.rrc_make(fs, rs, np.float32(alpha))
+        nsym = int(_pick(rng, [128, 128, 192, 256]))
+        L = nsym * cycles
+        G = 2 * int(rng.integers(2, 9))
+        F = G * int(rng.integers(256 - 256 // G + 1, 257))
     F = max(1, min(F, (2 * max_samples if big else max_samples) // L))
     mode = int(_pick(rng, [TIMING_FIXED, TIMING_FIXED, TIMING_HIST, TIMING_HIST, TIMING_FFT]))
     if mode == TIMING_FFT and (L < 128 + 512 + 126 or cycles not in (2, 4, 8)):   # the library's FFT estimate: CYCLES 2, 4, 8
