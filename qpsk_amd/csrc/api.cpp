@@ -676,13 +676,10 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
         if (G > pipe2_max_frames()) G = pipe2_max_frames();
         G += G & 1;
         /* above 16 frames per CU: always (the filter is the limit there).  Up to 16 frames per CU both kernels sit on the serial wave,
-         * and since round 5 (LDS-DMA staging, two-unit FIR waves) this one is ahead there too -- 0.1546 against 0.1575 ms at config 2,
-         * 1-2 % at 1024-3584 frames (profiles/r05_config2_lean.txt) -- for batches it takes in ONE launch (whole workgroups of at least
-         * four frames).  The FFT timing estimate inside the launch exists only in rx_fused_pipe_kernel: config 3's shape stays there. */
-        const bool fft_inline = c->prm.timing_mode == QPSK_TIMING_FFT && tuned(c->tune.fft_fused, 1) != 0 &&
-                                (long long)nframes > (long long)c->ncu * pipe_frames(pipe_max_nf() - 1) &&
-                                c->prm.frame_size >= timing_fft_first() + timing_fft_nfft();
-        const bool wanted = pipe_v == 3 || G > 16 || (G >= 4 && nframes % G == 0 && !fft_inline);
+         * and since round 5 (LDS-DMA staging, a window per unit, two-unit FIR waves) this one is ahead there too -- 0.1519 against 0.1560 ms
+         * at config 2, 1-2 % at 1024-3584 frames (profiles/r05_config2_lean.txt) -- for batches it takes in ONE launch (whole workgroups
+         * of at least four frames). */
+        const bool wanted = pipe_v == 3 || G > 16 || (G >= 4 && nframes % G == 0);
         unsigned long long layout = 0;
         if (c->tune.layout_lo >= 0 || c->tune.layout_hi >= 0)
             layout = ((unsigned long long)(unsigned)tuned(c->tune.layout_lo, 0) << 4) |
@@ -718,9 +715,10 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
      * from a launch in front (timing_fft_kernel / timing_scan_kernel / ...). */
     bool fused_fft = false;
     double *est_tw = nullptr, *est_cs = nullptr;
-    if (c->prm.timing_mode == QPSK_TIMING_FFT && main_pl.kind == K_FUSED_PIPE && main_pl.nf == pipe_max_nf() && rem_pl.nframes == 0 &&
-        nbw == 1 && tuned(c->tune.fft_fused, 1) != 0 && c->prm.frame_size >= timing_fft_first() + timing_fft_nfft() &&
-        !(tuned(c->tune.pipe_variant, 0) & (128 | 4))) {
+    if (c->prm.timing_mode == QPSK_TIMING_FFT && rem_pl.nframes == 0 && nbw == 1 && tuned(c->tune.fft_fused, 1) != 0 &&
+        c->prm.frame_size >= timing_fft_first() + timing_fft_nfft() &&
+        ((main_pl.kind == K_FUSED_PIPE && main_pl.nf == pipe_max_nf() && !(tuned(c->tune.pipe_variant, 0) & (128 | 4))) ||
+         (main_pl.kind == K_LEAN && lean_est_ok(a, main_pl.G, main_pl.layout)))) {
         int rt = fft_timing_tables(c, &est_tw, &est_cs);
         if (rt) return rt;
         fused_fft = true;
@@ -738,13 +736,13 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
 
     /* ---- the launches */
     auto execute = [&](const FusedArgs &fa, const Plan &pl) -> int {
-        /* only rx_fused_pipe_kernel's full workgroups look at est_tw; any other kernel would demodulate with fixed_index */
-        if (fa.est_tw && !(pl.kind == K_FUSED_PIPE && pl.nf == pipe_max_nf()))
+        /* only rx_fused_pipe_kernel's full workgroups and rx_lean_kernel look at est_tw; any other kernel would demodulate with fixed_index */
+        if (fa.est_tw && !(pl.kind == K_FUSED_PIPE && pl.nf == pipe_max_nf()) && pl.kind != K_LEAN)
             return fail(QPSK_ERR_STATE, "internal: in-launch FFT timing estimate planned for a kernel that has none");
         switch (pl.kind) {
         case K_LEAN:
             KERNEL_TRY(launch_rx_lean(fa, pl.G, pl.layout, c->d_status, c->stream));
-            c->last_kernel = "rx_lean_kernel";
+            c->last_kernel = fa.est_tw ? "rx_lean_kernel (FFT timing estimate inside the launch)" : "rx_lean_kernel";
             break;
         case K_PIPE2:
             KERNEL_TRY(launch_rx_pipe2(fa, pl.G, pl.layout, c->d_status, c->stream));

@@ -95,6 +95,7 @@ size_t lean_lds_bytes(int G, int nwin);
 unsigned long long lean_default_layout(int NU);         /* rx_lean_kernel: 1, 5, 5, 5 units on SIMDs 0-3 for a full workgroup */
 bool lean_shape_ok(const FusedArgs &a, int G);          /* one loop per frame, whole chunks, whole even workgroups, ... */
 int launch_rx_lean(const FusedArgs &a, int G, unsigned long long layout, int *status, hipStream_t s);
+bool lean_est_ok(const FusedArgs &a, int G, unsigned long long layout);   /* the FFT timing estimate inside rx_lean_kernel's launch fits this geometry */
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s, size_t in_pitch = 0);      /* in_pitch: samples between input frames (0 = length) */
 /* firstream.hip: the same filter as the generated stream fir_full8s_asm.h (SYMMETRIC taps only: the caller checks) */

@@ -1491,10 +1491,11 @@ static_assert(WS % 2 == 0 && pipe2::slot_of(pipe2::PAD * (pipe2::QL - 1) + pipe2
               pipe2::slot_of(pipe2::CH + HIST - 1) < WS + 16, "window: every position a lane reads, and a frame's spill stays in the next frame's history slots");
 __device__ __host__ constexpr int rows_of(int G) { return G > HW_WAVES ? G : HW_WAVES; }
 } // namespace lean
+constexpr size_t LEAN_EST_LDS_BYTES = 128 * sizeof(float) + 32 * sizeof(int);   /* in-launch FFT estimate: taps, the workgroup's indices */
 
 template <int NUW>
 __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm, unsigned char *rows, float2 *mywin,
-                                              int hwave, int u0, int f0, int lane, int nchunks, int *status)
+                                              int hwave, int u0, int f0, int lane, int nchunks, int *status, const int *est)
 {
     using namespace pipe2;
     using GM = lean::GeomLean;
@@ -1511,7 +1512,8 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
 #pragma unroll
         for (int ff = 0; ff < UF; ff++) {
             const int fr = f0 + UF * (u0 + ui) + ff;
-            const int ix = __builtin_amdgcn_readfirstlane(a.index ? a.index[fr] : a.fixed_index) & 7;   /* decimation offset, < C */
+            /* decimation offset, < C: the estimate made inside this launch (est[], in LDS), the caller's array, or the fixed one */
+            const int ix = __builtin_amdgcn_readfirstlane(est ? est[UF * (u0 + ui) + ff] : a.index ? a.index[fr] : a.fixed_index) & 7;
             ixpack |= (unsigned)ix << (4 * (2 * ui + ff));
         }
     /* which stream this wave runs (wave-uniform): LDS-DMA staging needs even offsets (16-byte pairs); a two-unit wave that stages by
@@ -1664,6 +1666,43 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
 
     if (tid < MAX_WAVES) sm->ready[tid] = 0;
     if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
+    /* ---- BASELINE config 3: the FFT timing estimate inside the launch (timing_fft_wave.h), as in rx_fused_pipe_kernel: every hardware
+     * wave of the workgroup -- the serial wave and waves that own no unit included, all idle until the first chunk exists -- estimates
+     * frames wave, wave + nwe, ... of the workgroup (at most MAX_FPW each): one pass of the full-rate stream fir_full8_asm.h over 512
+     * samples, the symbol-rate bin of fft.c's transform, the argmax rule; its window lies in the (not yet used) frame windows, the taps
+     * and the indices in 640 bytes behind the ring rows.  No launch of its own, no drain and refill of the chip in between. */
+    const int *est = nullptr;
+    if (a.est_tw) {
+        float *etaps = reinterpret_cast<float *>(rows + (size_t)lean::rows_of(G) * lean::ROW_BYTES);
+        int *eidx = reinterpret_cast<int *>(etaps + 128);
+        for (int i = tid; i < 128; i += blockDim.x) etaps[i] = i < NTAPS ? a.taps[i] : 0.0f;
+        __syncthreads();
+        const int nw = (int)blockDim.x / 64;
+        const int room = (int)((size_t)nwin * UF * lean::WS / tfft::WSLOTS);       /* estimator windows the frame windows hold */
+        const int nwe = nw < room ? nw : room;
+        if (wave < nwe) {
+            float2 *ewin = win + (size_t)wave * tfft::WSLOTS;
+            const unsigned erd = lds_addr(ewin + (tfft::R + tfft::PADS) * lane), etap = lds_addr(etaps);
+            tfft::Pre5 pre = tfft::load_frame5(a.x + (size_t)min(f0 + wave, a.nframes - 1) * a.frame_pitch, lane);
+            for (int fe = wave; fe < G; fe += nwe) {
+                tfft::stage_frame5(ewin, lane, pre);
+                if (fe + nwe < G) pre = tfft::load_frame5(a.x + (size_t)min(f0 + fe + nwe, a.nframes - 1) * a.frame_pitch, lane);
+                tfft::wave_sync();
+                v2f e0, e1, e2, e3, e4, e5, e6, e7;
+                fir_full8_asm(erd, etap, e0, e1, e2, e3, e4, e5, e6, e7);
+                const v2f eacc[tfft::R] = {e0, e1, e2, e3, e4, e5, e6, e7};
+                double epv[tfft::R];
+                const tfft::cd u = tfft::power_bin(eacc, ewin, lane, a.est_tw, tfft::NFFT / C, nullptr, epv);
+                if (lane == 0) {
+                    const int best = tfft::pick_index(u, a.est_cs, C, nullptr);
+                    eidx[fe] = best;
+                    if (a.index_out && f0 + fe < a.nframes) a.index_out[f0 + fe] = best;
+                }
+                tfft::wave_sync();
+            }
+        }
+        est = eidx;
+    }
     __syncthreads();
 
     if (wave == 0) {   /* a.mixed == 2: lane g waits on ready[g / 2] */
@@ -1671,7 +1710,7 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
                         f0, lane, nchunks, status);
         return;
     }
-    const int mine = (int)((layout >> (4 * wave)) & 15);
+    const int mine = wave < 16 ? (int)((layout >> (4 * wave)) & 15) : 0;
     if (mine == 0) return;
     int u0 = 0, widx = 0;
     for (int v = 1; v < wave; v++) {
@@ -1681,9 +1720,9 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
     }
     float2 *mywin = win + (size_t)widx * UF * lean::WS;
     if (mine == 2)
-        fir_wave_lean<2>(a, sm, rows, mywin, wave, u0, f0, lane, nchunks, status);
+        fir_wave_lean<2>(a, sm, rows, mywin, wave, u0, f0, lane, nchunks, status, est);
     else
-        fir_wave_lean<1>(a, sm, rows, mywin, wave, u0, f0, lane, nchunks, status);
+        fir_wave_lean<1>(a, sm, rows, mywin, wave, u0, f0, lane, nchunks, status, est);
 }
 
 size_t lean_lds_bytes(int G, int nwin)
@@ -1726,10 +1765,28 @@ bool lean_shape_ok(const FusedArgs &a, int G)
            !(a.dbg & (8 | 16));
 }
 
+/* can rx_lean_kernel run the FFT timing estimate inside its launch at this geometry?  (launch_rx_lean's own rule: api.cpp asks, it does
+ * not restate) */
+bool lean_est_ok(const FusedArgs &a, int G, unsigned long long layout)
+{
+    using namespace pipe2;
+    int units = 0, nwin = 0, hw = 1;
+    for (int w = 1; w < 16; w++) {
+        const int cw = (int)((layout >> (4 * w)) & 15);
+        units += cw;
+        nwin += cw != 0;
+        if (cw) hw = w + 1;
+    }
+    if (a.lean_twowin && a.lean_dma && units > nwin && lean_lds_bytes(G, units) <= (size_t)MAX_LDS_BYTES) nwin = units;
+    if (hw < 8) hw = 8;
+    const int room = (int)((size_t)nwin * UF * lean::WS / tfft::WSLOTS), nwe = hw < room ? hw : room;
+    return a.frame_size >= tfft::N0 + tfft::NFFT && nwe >= 1 && (G + nwe - 1) / nwe <= tfft::MAX_FPW && G <= 32 &&
+           lean_lds_bytes(G, nwin) + LEAN_EST_LDS_BYTES <= (size_t)MAX_LDS_BYTES;
+}
+
 int launch_rx_lean(const FusedArgs &a0, int G, unsigned long long layout, int *status, hipStream_t s)
 {
     using namespace pipe2;
-    if (a0.est_tw) return (int)hipErrorInvalidValue;   /* no in-launch timing estimate in this kernel: it would use fixed_index */
     FusedArgs a = a0;
     int units = 0, nwin = 0, hw = 1;
     for (int w = 1; w < 16; w++) {
@@ -1747,7 +1804,18 @@ int launch_rx_lean(const FusedArgs &a0, int G, unsigned long long layout, int *s
     /* a window per UNIT where the LDS has the room (up to 16 frames per workgroup; a.lean_twowin comes in as the caller's wish) */
     a.lean_twowin = a.lean_twowin && a.lean_dma && units > nwin && lean_lds_bytes(G, units) <= (size_t)MAX_LDS_BYTES;
     if (a.lean_twowin) nwin = units;
-    hipLaunchKernelGGL(rx_lean_kernel, dim3(a.nframes / G), dim3(64 * hw), lean_lds_bytes(G, nwin), s, a, layout, nwin, status);
+    size_t lds = lean_lds_bytes(G, nwin);
+    if (a.est_tw) {
+        /* the FFT timing estimate inside the launch: at least eight hardware waves share the workgroup's frames (waves without a unit
+         * retire after it), at most MAX_FPW frames per wave, estimator windows in the frame windows, taps + indices behind the rows */
+        if (hw < 8) hw = 8;
+        const int room = (int)((size_t)nwin * UF * lean::WS / tfft::WSLOTS), nwe = hw < room ? hw : room;
+        lds += LEAN_EST_LDS_BYTES;
+        if (!a.est_cs || a.index || a.frame_size < tfft::N0 + tfft::NFFT || nwe < 1 || (G + nwe - 1) / nwe > tfft::MAX_FPW ||
+            G > 32 || lds > (size_t)MAX_LDS_BYTES)
+            return (int)hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(rx_lean_kernel, dim3(a.nframes / G), dim3(64 * hw), lds, s, a, layout, nwin, status);
     return (int)hipGetLastError();
 }
 

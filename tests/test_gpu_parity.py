@@ -118,16 +118,22 @@ def test_rx_batch_fft_timing(oracle, fs, rs, L, F):
     assert np.all(want["index"][:F - 2] == 126 % m.cycles)
 
 
-@pytest.mark.parametrize("tune,kernel", [(dict(pipe_g=32), "rx_lean_kernel"), (dict(pipe_g=20), "rx_lean_kernel"),
-                                         (dict(pipe_v=2), "rx_pipe2_kernel"), (dict(pipe_v=3), "rx_lean_kernel"),
-                                         (dict(pipe_nf=2), "rx_fused_pipe_kernel"), (dict(fused_generic=1), "rx_fused_kernel"),
-                                         (dict(fft_fused=0), "rx_lean_kernel"), (dict(pipe_dbg=128), "rx_fused_pipe_kernel"),
-                                         (dict(), "rx_fused_pipe_kernel (FFT timing estimate inside the launch)")])
+INLINE = " (FFT timing estimate inside the launch)"
+
+
+@pytest.mark.parametrize("tune,kernel", [(dict(pipe_g=32), "rx_lean_kernel"), (dict(pipe_g=20), "rx_lean_kernel"), (dict(pipe_g=8), "rx_lean_kernel" + INLINE),
+                                         (dict(pipe_v=2), "rx_pipe2_kernel"), (dict(pipe_v=3), "rx_lean_kernel" + INLINE),
+                                         (dict(pipe_v=1), "rx_fused_pipe_kernel" + INLINE), (dict(pipe_v=1, pipe_nf=2), "rx_fused_pipe_kernel"),
+                                         (dict(fused_generic=1), "rx_fused_kernel"), (dict(lean_dma=0), "rx_lean_kernel" + INLINE),
+                                         (dict(fft_fused=0), "rx_lean_kernel"), (dict(pipe_v=1, pipe_dbg=128), "rx_fused_pipe_kernel"),
+                                         (dict(), "rx_lean_kernel" + INLINE)])
 def test_fft_timing_under_every_geometry_key(oracle, tune, kernel):
     """No tuning key may change a result (include/qpsk_hip.h).  Round 4's host code restated the kernel choice to decide whether the
     FFT estimate runs inside the receive launch and missed QPSK_PIPE_G: with G above 16 the batch went to rx_lean_kernel, which has no
     estimate, with no index computed -- silently wrong symbols.  The plan is now made once and the estimate's placement reads it: the
-    FFT-timed batch under every key that moves it to another kernel, against the oracle, the index included."""
+    FFT-timed batch under every key that moves it to another kernel, against the oracle, the index included.  (QPSK_PIPE_G = 32 fills the
+    LDS: no room for the estimate's 640 bytes; 20 frames per workgroup leave a last partial workgroup for another kernel: the estimate
+    then runs in front of both.)"""
     from oracle.pyoracle import TIMING_FFT
     fs, rs, L, F = 19200.0, 2400.0, 1024, 4096        # 4096 frames = 16 per CU: the in-launch estimate's shape when nothing is set
     m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT, fixed_index=3)     # a fixed_index that is NOT the estimate (6)
