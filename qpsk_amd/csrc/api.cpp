@@ -72,7 +72,7 @@ struct Tuning {
     int stream_poll = -1;                             /* qpsk_streams_rx_pcm_host on the one-launch kernel: 0 = wait with hipStreamSynchronize instead of watching the kernel's counter */
     int stream_block = -1;                            /* streams: 0 = never the one-launch-per-block kernel (streamblock.hip), 1 = whenever the shape allows, unset: by samples per block of all streams (stream_block_ok: 3.5 M for PCM, 0.4 M for complex input at CYCLES 8) */
     int stream_carrier = -1;                          /* stream_scan_kernel on PCM: 0 = every stream runs its own carrier (mixer wave) even while all streams share one */
-    int lean_dma = -1;                                /* rx_lean_kernel: 0 = window staging through registers even where LDS-DMA applies (even decimation offsets) */
+    int lean_dma = -1;                                /* rx_lean_kernel: 0 = window staging through registers even where LDS-DMA applies (even decimation offsets), 2 = LDS-DMA with one window per FIR wave */
     int fft_fused = -1;                               /* FFT timing estimate: 0 = always a launch of its own (1 / unset: inside rx_fused_pipe_kernel's launch for full workgroups) */
 };
 
