@@ -1539,7 +1539,11 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
                  * the visit order of the batch in memory is what is measured) */
                 if (a.dbg & 2097152) fsrc = (size_t)(UF * u + ff) * gridDim.x + blockIdx.x;
 #endif
-                const unsigned long long src = (unsigned long long)(a.x + fsrc * a.frame_pitch);
+                unsigned long long src = (unsigned long long)(a.x + fsrc * a.frame_pitch);
+#ifdef QPSK_PIPE_PROFILE
+                /* measurement build, dbg bit 22: the workgroup's frames as one contiguous tile per chunk (see gen_lean_asm.py, "tiled") */
+                if (a.dbg & 4194304) src = (unsigned long long)(a.x + (size_t)f0 * a.frame_pitch) + (unsigned long long)(UF * u + ff) * 4096ull;
+#endif
                 prm[4 * ui + 2 * ff] = (unsigned)src;
                 prm[4 * ui + 2 * ff + 1] = (unsigned)(src >> 32);
             }
@@ -1578,7 +1582,7 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
             printf("wg %3d FIR wave hw %2d (%d units): %d chunks, %llu cycles in the stream; per chunk: samples %u, stage+loads %u, "
                    "filter+gain %u, wait for the loop %u, flush %u, hand-over %u\n", (int)blockIdx.x, hwave, NUW, nchunks, t1 - t0,
                    pf[0] / nchunks, pf[1] / nchunks, pf[2] / nchunks, pf[3] / nchunks, pf[4] / nchunks, pf[5] / nchunks);
-    } else if (a.dbg & (1 | 16384 | 32768 | 65536 | 262144 | 524288 | 1048576)) {
+    } else if (a.dbg & (1 | 16384 | 32768 | 65536 | 262144 | 524288 | 1048576 | 4194304)) {
         /* measurement build: streams with a part of the work left out (WRONG results): 1 the filter's multiplies and adds,
          * 16384 its window reads, 32768 the flush's arithmetic, 65536 the window staging writes, 262144 the symbol stores, 524288 the
          * hand-over write of the symbols -- what each costs in time and in energy at the board's power limit (one at a time: the
@@ -1592,6 +1596,7 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
         else if (a.dbg & 65536) st = QPSK_LEAN_ABLATED(astage);
         else if (a.dbg & 262144) st = QPSK_LEAN_ABLATED(astore);
         else if (a.dbg & 524288) st = QPSK_LEAN_ABLATED(aring);
+        else if (a.dbg & 4194304) st = QPSK_LEAN_ABLATED(atiled);
         else st = QPSK_LEAN_ABLATED(aorder);
 #undef QPSK_LEAN_ABLATED
     } else

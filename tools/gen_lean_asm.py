@@ -66,6 +66,8 @@ PROFILE = False
 # two blocks; "flush": no sin/cos redo, rotation, slicer arithmetic; "stage": no window staging writes.  Round 5:
 #   "store"  no symbol stores (the flush's global_store_short);        "ring"  no hand-over write of the unit's symbols (counter kept);
 #   "order"  the unit's eight loads issued frame-alternating (1 KB visits instead of 4 KB per frame);
+#   "tiled"  a workgroup's 32 frames read as ONE contiguous 128 KB tile per chunk (frame g's 4 KB at g x 4 KB, the next chunk 128 KB on): what a
+#            chunk-major batch layout would do to the memory side (the kernel points the source pointers at such tiles of the SAME buffer: wrong data);
 #   DMA = True (not an ablation: fir_lean_loop*_dma of the product header)
 #            window staging by LDS-DMA: blocks 0..2 of a frame's 512 new samples go HBM -> LDS directly (four global_load_lds_dwordx4
 #            per frame, per-lane source offsets that realise the padded window image, the last one on 24 lanes), issued when the
@@ -304,7 +306,7 @@ def loads(e, u):
                 e("global_load_dwordx4 %s, %%[voff], %s offset:%d nt", v4(PRE + 16 * ff + 4 * j), sp(SRC + 4 * u + 2 * ff), 1024 * j)
     for ff in range(2):
         s = SRC + 4 * u + 2 * ff
-        e("s_add_u32 s%d, s%d, 0x1000", s, s)
+        e("s_add_u32 s%d, s%d, 0x%x", s, s, 0x20000 if ABLATE == "tiled" else 0x1000)
         e("s_addc_u32 s%d, s%d, 0", s + 1, s + 1)
 
 
@@ -622,7 +624,7 @@ constexpr int FIR_LEAN_NPROF = %d;
     print(emit_function(1))
     print(emit_function(2))
     global ABLATE
-    for ABLATE in ("valu", "lds", "flush", "stage", "store", "ring", "order"):
+    for ABLATE in ("valu", "lds", "flush", "stage", "store", "ring", "order", "tiled"):
         print(emit_function(1))
         print(emit_function(2))
     ABLATE = None
