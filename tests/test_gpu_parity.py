@@ -148,6 +148,25 @@ def test_fft_timing_under_every_geometry_key(oracle, tune, kernel):
     assert np.all(want["index"][:5] == 6)
 
 
+@pytest.mark.parametrize("F", [1024, 2560, 3584, 4608, 5632, 8192])
+def test_fft_timing_inside_rx_lean_kernel_at_every_workgroup_size(oracle, F):
+    """the FFT estimate inside rx_lean_kernel's launch at 4, 10, 14, 18 and 22 frames per workgroup (one window per FIR wave, a window per
+    unit, eight to twelve hardware waves sharing the estimate) -- and at 32, where the LDS has no room for it and it runs in front:
+    per-frame offsets of every value (frames delayed by 0..7 samples), against the oracle"""
+    from oracle.pyoracle import TIMING_FFT
+    fs, rs, L = 19200.0, 2400.0, 1024
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT)
+    x, _ = make_frames(F, L + 8, 8, m.taps, fs, offset_hz=30.0, base_seed=13, noise=0.05)
+    x = np.stack([x[f, (f % 8):(f % 8) + L] for f in range(F)])
+    x[3] = random_frames(1, L, seed=6)[0]
+    got = m.rx_batch(x)
+    m.sync()
+    assert m.last_kernel() == ("rx_lean_kernel" if F == 8192 else "rx_lean_kernel" + INLINE), m.last_kernel()
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FFT, threads=min(16, os.cpu_count() or 1))
+    assert len(np.unique(want["index"])) == 8
+    assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz"))
+
+
 def test_rx_batch_tilings_agree(oracle):
     """results do not depend on how frames are grouped into workgroups / chunks"""
     fs, rs, L, F = 19200.0, 2400.0, 2048, 50
