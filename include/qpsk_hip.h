@@ -113,7 +113,9 @@ int qpsk_ctx_set_stream(qpsk_ctx *ctx, void *stream);
  * timing: 1 = mixer + filter + scan as one kernel whatever the stream count, 0 = never), "QPSK_STREAM_CARRIER" (0: that kernel runs every
  * stream's carrier recurrence although all streams share one), "QPSK_LEAN_DMA" (0: rx_lean_kernel stages its filter windows through
  * registers even where it would use LDS-DMA: frames with an even timing offset; 2: LDS-DMA, but one window per FIR wave even where the LDS
- * has room for one per two-frame unit); value < 0 = back to the library's own choice.
+ * has room for one per two-frame unit), "QPSK_LEAN_PAIR" (rx_lean_kernel's serial wave: 0 = one lane per Costas loop, 1 = two lanes per
+ * loop -- they share the step's sine / cosine polynomial chains -- in workgroups of up to 16 frames, 2 = up to 32; the library's own choice is up to 24); value < 0 = back to
+ * the library's own choice.
  * Environment variables of the same names are read once, by qpsk_ctx_create(), as the context's initial values;
  * no other call reads the environment, and none of them can change a result. */
 int qpsk_ctx_set_tuning(qpsk_ctx *ctx, const char *name, int value);

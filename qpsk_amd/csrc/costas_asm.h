@@ -10,7 +10,10 @@
  * pads with s_nop), ~16-21 per LDS instruction almost regardless of its size (16 -> 12 -> 4 bytes per step: -2.4 %,
  * then -1 %; one write per 16 steps instead of one per step: -8 %), 13-15 for the per-step wrap test's branch with
  * the wraps it takes.  The compiler's version of the step ran ~355 cycles.  What this stream does about it:
- *   - 28 VALU instructions per step;
+ *   - 28 VALU instructions per step (26 in the paired-lane form below), as few of them 8-byte encodings as the ISA allows: the
+ *     range reduction is v_mul_f64 + v_rndne_f64 (VOP1) + v_fmac_f64 (VOP2: gfx90a on) in place on the argument, the sine's last
+ *     stage a v_fmac_f64 in place on the reduced argument (round 6; n = rndne(fl(x 2/pi)) equals the magic-number rounding
+ *     of round 1-5 for every float in [-8, 8]: tools/check_device_sincos.cpp --stream, tests/test_sincos.py);
  *   - the only thing a step leaves behind is the PHASE it started from (the FIR waves' flush redoes sin/cos and
  *     the rotation from it, bit for bit the same operations): four steps' phases sit in v140..v143 and go to LDS
  *     in one ds_write_b128, so the wave issues 0.75 LDS instructions per step (two symbols per ds_read_b128,
@@ -51,9 +54,9 @@
  *
  * Registers: v[100:143] are scratch owned by the block (clobbered; low enough for a kernel built for three
  * waves per SIMD, i.e. at most 168 VGPRs):
- *   100:101 x / d*C      102:103 beta*d, alpha*d   104:105 n / x3 / d*S     106:107 xr / d
+ *   100:101 d*C (paired form: M, then C | S)      102:103 beta*d, alpha*d   104:105 x 2/pi -> n / x3 / d*S     106:107 x -> xr -> S / d
  *   108:109 x2 / s       110:111 cos chain (v110 = C)   112:113 sin chain (v112 = S)
- *   114:115 T            116:117 the magic sum of the range reduction
+ *   114:115 T            116:117 free
  *   118 freq (clamped in place by the next step's head)    120:123, 136:139 two pairs of decimated symbols   126 running min
  *   127 2pi hi   128:129 +-2pi   130,131 group-start phase/freq
  *   140:143 the phases of four consecutive steps (step k in v140 + k % 4) = their records
@@ -84,28 +87,61 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 #define QPSK_STR_(x) #x
 #define QPSK_STR(x) QPSK_STR_(x)
 
-/* head of a step: phase PIN -> n (v116 low bits), xr = PIN - n pi/2 (v106:107), xr^2 (v108:109) */
+/* head of a step: phase PIN -> x = (double)PIN in v[106:107], n = rndne(x 2/pi) (v[104:105]), xr = x - n pi/2 IN PLACE
+ * (v_fmac_f64: a 4-byte VOP2 encoding, like v_rndne_f64's VOP1), xr^2 (v108:109), the first row of each polynomial chain */
 #define QPSK_HEAD_CHAIN(PIN)                                                                                  \
-    "v_cvt_f64_f32 v[100:101], " PIN "\n\t"                                                                   \
-    "v_fma_f64 v[116:117], v[100:101], %[k2pi], %[magic]\n\t"                                                 \
-    "v_add_f64 v[104:105], v[116:117], -%[magic]\n\t"                                                         \
-    "v_fma_f64 v[106:107], -v[104:105], %[hpi], v[100:101]\n\t"                                               \
-    "v_mul_f64 v[108:109], v[106:107], v[106:107]\n\t"
+    "v_cvt_f64_f32 v[106:107], " PIN "\n\t"                                                                   \
+    "v_mul_f64 v[104:105], v[106:107], %[k2pi]\n\t"                                                           \
+    "v_rndne_f64_e32 v[104:105], v[104:105]\n\t"                                                              \
+    "v_fmac_f64_e32 v[106:107], %[nhpi], v[104:105]\n\t"                                                      \
+    "v_mul_f64 v[108:109], v[106:107], v[106:107]\n\t"                                                        \
+    "v_fma_f64 v[110:111], v[108:109], %[c4], %[c3]\n\t"                                                      \
+    "v_fma_f64 v[112:113], v[108:109], %[s3], %[s2]\n\t"
 
 /*
- * the same head with an independent instruction in four of its five empty issue slots: the 2*pi test of its phase
- * PIN and the previous step's leftovers -- its frequency clamp (v118, in place: this step's input) and its exact-zero
- * test.  The head runs on the unwrapped PIN; LW (QPSK_WRAP_HEAD) wraps PIN in place, redoes the head, returns to LR.
+ * A step of the one-lane stream in front of its wrap branch: the 2*pi test of its phase PIN FIRST (the branch waits for the
+ * compare's VCC: see QPSK_STEP_P_PRE), the head with the previous step's leftovers in between -- its frequency clamp (v118, in
+ * place: this step's input) and its exact-zero test -- and the first rows of the two polynomial chains.  Everything here is a pure
+ * function of PIN or idempotent: LW (QPSK_WRAP_HEAD) wraps PIN in place, runs it again, returns to LR.
  */
-#define QPSK_HEAD_DEFERRED(PIN, LW, LR)                                                                      \
-    "v_cvt_f64_f32 v[100:101], " PIN "\n\t"                                                                   \
-    "v_cmp_ge_f32_e64 vcc, |" PIN "|, %[tau]\n\t"                                                             \
-    "v_fma_f64 v[116:117], v[100:101], %[k2pi], %[magic]\n\t"                                                 \
+#define QPSK_CMP_P(PIN) "v_cmp_ge_f32_e64 vcc, |" PIN "|, %[tau]\n\t"
+#define QPSK_STEP_1_PRE(CMP, PIN)                                                                             \
+    CMP                                                                                                       \
+    "v_cvt_f64_f32 v[106:107], " PIN "\n\t"                                                                   \
+    "v_mul_f64 v[104:105], v[106:107], %[k2pi]\n\t"                                                           \
     "v_med3_f32 v118, v118, %[fmin], %[fmax]\n\t"                                                             \
-    "v_add_f64 v[104:105], v[116:117], -%[magic]\n\t"                                                         \
+    "v_rndne_f64_e32 v[104:105], v[104:105]\n\t"                                                              \
     "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
-    "v_fma_f64 v[106:107], -v[104:105], %[hpi], v[100:101]\n\t"                                               \
+    "v_fmac_f64_e32 v[106:107], %[nhpi], v[104:105]\n\t"                                                      \
     "v_mul_f64 v[108:109], v[106:107], v[106:107]\n\t"                                                        \
+    "v_fma_f64 v[110:111], v[108:109], %[c4], %[c3]\n\t"                                                      \
+    "v_fma_f64 v[112:113], v[108:109], %[s3], %[s2]\n\t"
+#define QPSK_HEAD_DEFERRED(PIN, LW, LR)                                                                      \
+    QPSK_STEP_1_PRE(QPSK_CMP_P(PIN), PIN)                                                                     \
+    "s_cbranch_vccnz " LW "f\n"                                                                               \
+    LR ":\n\t"
+
+/*
+ * The paired-lane stream's step in front of its wrap branch (PRE) and behind it (QPSK_BODY_P).  The branch waits for the compare's VCC:
+ * measured with the stream alone on a CU (tools/ubench_step.py, profiles/r06_step_cost.txt), a step costs 165.6 cycles with the branch
+ * right behind the compare, 160.6 two instructions on, 148.3 five on, 146.1 nine on and 150-154 later still (where the branch falls in
+ * the fetch lines moves it by +-3), so the 2*pi test is the step's FIRST instruction and the branch stands nine instructions behind it:
+ * everything in between is a pure function of PIN (the out-of-line wrap corrects PIN and runs PRE again).
+ */
+#define QPSK_STEP_P_PRE(CMP, PIN)                                                                             \
+    CMP                                                                                                       \
+    "v_cvt_f64_f32 v[106:107], " PIN "\n\t"                                                                   \
+    "v_mul_f64 v[104:105], v[106:107], %[k2pi]\n\t"                                                           \
+    "v_rndne_f64_e32 v[104:105], v[104:105]\n\t"                                                              \
+    "v_fmac_f64_e32 v[106:107], %[nhpi], v[104:105]\n\t"                                                      \
+    "v_mul_f64 v[108:109], v[106:107], v[106:107]\n\t"                                                        \
+    "v_fma_f64 v[100:101], v[106:107], %[km], %[kj]\n\t"                                                      \
+    "v_fma_f64 v[110:111], v[108:109], %[ka], %[kb]\n\t"                                                      \
+    "v_mul_f64 v[104:105], v[108:109], v[100:101]\n\t"                                                        \
+    "v_fma_f64 v[110:111], v[108:109], v[110:111], %[kc]\n\t"
+#define QPSK_HEAD_CHAIN_P(PIN) QPSK_STEP_P_PRE("", PIN)
+#define QPSK_HEAD_DEFERRED_P(PIN, LW, LR)                                                                    \
+    QPSK_STEP_P_PRE(QPSK_CMP_P(PIN), PIN)                                                                     \
     "s_cbranch_vccnz " LW "f\n"                                                                               \
     LR ":\n\t"
 
@@ -117,17 +153,8 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
  * (profiles/r03_ubench_fetch.txt: 4.15 cycles per 4-byte instruction, 5.14 per 8-byte one, 5.75 for v_fma_f32).  DREG = the VGPR pair holding this step's symbol, WAIT = the lgkmcnt wait in front of
  * its first use, READ = the LDS fetch of the pair after next (even steps) or nothing.
  */
-#define QPSK_BODY(PIN, POUT, DREG, WAIT, READ, QW)                                                            \
-    "v_fma_f64 v[110:111], v[108:109], %[c4], %[c3]\n\t"                                                      \
-    "v_fma_f64 v[112:113], v[108:109], %[s3], %[s2]\n\t"                                                      \
-    "v_fma_f64 v[110:111], v[108:109], v[110:111], %[c2]\n\t"                                                 \
-    "v_mul_f64 v[104:105], v[106:107], v[108:109]\n\t"                                                        \
-    "v_fma_f64 v[110:111], v[108:109], v[110:111], %[c1]\n\t"                                                 \
-    "v_fma_f64 v[112:113], v[108:109], v[112:113], %[s1]\n\t"                                                 \
-    "v_fma_f64 v[110:111], v[108:109], v[110:111], 1.0\n\t"                                                   \
-    "v_fma_f64 v[112:113], v[104:105], v[112:113], v[106:107]\n\t"                                            \
-    "v_cvt_f32_f64 v110, v[110:111]\n\t"                                                                      \
-    "v_cvt_f32_f64 v112, v[112:113]\n\t"                                                                      \
+/* the fp32 part of a step, from C in v110 and S in v112 */
+#define QPSK_BODY_F32(PIN, POUT, DREG, WAIT, READ, QW)                                                        \
     WAIT                                                                                                      \
     "v_pk_mul_f32 v[100:101], " DREG ", v[110:111] op_sel_hi:[1,0]\n\t"                                       \
     "v_pk_mul_f32 v[104:105], " DREG ", v[112:113] op_sel:[1,0] op_sel_hi:[0,0]\n\t"                          \
@@ -142,6 +169,43 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
     "v_add_f32_e32 " POUT ", " PIN ", v118\n\t"                                                               \
     "v_fmac_f32_e32 " POUT ", v108, v103\n\t"                 /* (phase + freq) + alpha e */
 
+#define QPSK_BODY(PIN, POUT, DREG, WAIT, READ, QW)                                                            \
+    "v_fma_f64 v[110:111], v[108:109], v[110:111], %[c2]\n\t"                                                 \
+    "v_mul_f64 v[104:105], v[106:107], v[108:109]\n\t"                                                        \
+    "v_fma_f64 v[110:111], v[108:109], v[110:111], %[c1]\n\t"                                                 \
+    "v_fma_f64 v[112:113], v[108:109], v[112:113], %[s1]\n\t"                                                 \
+    "v_fma_f64 v[110:111], v[108:109], v[110:111], 1.0\n\t"                                                   \
+    "v_fmac_f64_e32 v[106:107], v[104:105], v[112:113]\n\t"   /* S = xr + x3 q, in place on xr */                \
+    "v_cvt_f32_f64 v110, v[110:111]\n\t"                                                                      \
+    "v_cvt_f32_f64 v112, v[106:107]\n\t"                                                                      \
+    QPSK_BODY_F32(PIN, POUT, DREG, WAIT, READ, QW)
+
+/*
+ * The paired-lane body (round 6): lanes 2f and 2f + 1 run the SAME loop and hold the same state; the two Horner chains of the
+ * step -- 4 + 4 fp64 operations -- are ONE chain of per-lane coefficients: the even lane evaluates the cosine, the odd lane the sine,
+ *     M  = fma(xr, km, kj)     = 1                | xr          (km, kj) = (0, 1) | (1, -0): exact
+ *     r  = fma(x2, ka, kb)     = fma(x2, c4, c3)  | s3          ka = c4 | 0: x2 0 + s3 = s3 exactly
+ *     A  = x2 M                = x2               | x3 = xr x2  (the product the one-lane form rounds, commuted)
+ *     r  = fma(x2, r, kc), fma(x2, r, kd)          kc, kd = c2, c1 | s2, s1
+ *     M += A r  (v_fmac_f64)   = fma(x2, r, 1)    | fma(x3, r, xr)
+ * i.e. per value the operations of QPSK_BODY, so the exhaustive device check of the one-lane form covers it.  One DPP
+ * multiply then hands each lane its partner's value: the even lane holds (C, S); the odd lane (S, -C) (sg = 1 | -1), the pair
+ * of the phase turned by three quarter turns, so its T is the even lane's turned by one -- (-T.y, T.x), bit for bit: negation
+ * and swapping commute with every rounding involved -- and the detector takes the same value on it (qpsk_device.h, costas_step_t;
+ * the exact-zero test covers the one case where it does not, in both lanes alike).  From there both lanes run the same fp32
+ * instructions on their own T and arrive at the same frequency and phase: no way back is needed.  A VALU write needs two wait
+ * states before a DPP read of it: the previous step's clamp and zero test stand there.  26 VALU instructions per step.  The first
+ * four rows below stand in QPSK_STEP_P_PRE, in front of the step's wrap branch; QPSK_BODY_P is the rest.
+ */
+#define QPSK_BODY_P(PIN, POUT, DREG, WAIT, READ, QW)                                                          \
+    "v_fma_f64 v[110:111], v[108:109], v[110:111], %[kd]\n\t"                                                 \
+    "v_fmac_f64_e32 v[100:101], v[104:105], v[110:111]\n\t"                                                   \
+    "v_cvt_f32_f64 v110, v[100:101]\n\t"                                                                      \
+    "v_med3_f32 v118, v118, %[fmin], %[fmax]\n\t"                                                             \
+    "v_min3_f32 v126, v126, |v114|, |v115|\n\t"                                                               \
+    "v_mul_f32_dpp v112, v110, %[sg] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                      \
+    QPSK_BODY_F32(PIN, POUT, DREG, WAIT, READ, QW)
+
 /* the leftovers of a group's LAST step, in line: clamp -> FOUT, zero test, 2*pi test of POUT */
 #define QPSK_TAIL(POUT, FOUT, LW, LR)                                                                         \
     "v_cmp_ge_f32_e64 vcc, |" POUT "|, %[tau]\n\t"                                                            \
@@ -152,6 +216,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 
 /* costas_loop.c:61-67 for the lanes in vcc: P -= copysign(2pi, P) in fp64, once; still outside -> flag */
 #define QPSK_WRAP_ONCE(P)                                                                                     \
+    "v_cvt_f64_f32 v[100:101], " P "\n\t"                                                                     \
     "v_bfi_b32 v129, %[absm], v127, " P "\n\t"                                                                \
     "v_add_f64 v[100:101], v[100:101], -v[128:129]\n\t"                                                       \
     "v_cvt_f32_f64 v104, v[100:101]\n\t"                                                                      \
@@ -159,18 +224,23 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
     "v_cmp_ge_f32_e64 vcc, |" P "|, %[tau]\n\t"                                                               \
     "s_or_b64 %[fl], %[fl], vcc\n\t"
 
-/* out-of-line wrap for QPSK_HEAD_DEFERRED: v[100:101] still holds (double)PIN; wrap PIN where it stands (the
- * record written later is the WRAPPED phase, the one the step uses), then the head again */
+/* out-of-line wrap for QPSK_HEAD_DEFERRED: wrap PIN where it stands (the record written later is the WRAPPED phase, the
+ * one the step uses), then the head again */
 #define QPSK_WRAP_HEAD(PIN, LW, LR)                                                                           \
     LW ":\n\t"                                                                                                \
     QPSK_WRAP_ONCE(PIN)                                                                                       \
-    QPSK_HEAD_CHAIN(PIN)                                                                                      \
+    QPSK_STEP_1_PRE("", PIN)                                                                                  \
+    "s_branch " LR "b\n"
+/* ... for QPSK_HEAD_DEFERRED_P: what stood in front of its branch again */
+#define QPSK_WRAP_HEAD_P(PIN, LW, LR)                                                                         \
+    LW ":\n\t"                                                                                                \
+    QPSK_WRAP_ONCE(PIN)                                                                                       \
+    QPSK_STEP_P_PRE("", PIN)                                                                                  \
     "s_branch " LR "b\n"
 
 /* out-of-line wrap for QPSK_TAIL */
 #define QPSK_WRAP_TAIL(POUT, LW, LR)                                                                          \
     LW ":\n\t"                                                                                                \
-    "v_cvt_f64_f32 v[100:101], " POUT "\n\t"                                                                  \
     QPSK_WRAP_ONCE(POUT)                                                                                      \
     "s_branch " LR "b\n"
 
@@ -190,15 +260,16 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 /* four steps k = 4m .. 4m+3 (k > 0): the phase of step k lives in v140 + k % 4, the clamped frequency in v133
  * (odd k) or v135 (even k); SA/SB = the symbol sets of the first and the second pair, RD1/RD2 the fetches of the
  * two even steps, QOFF the byte offset of the four records, P4 where the fourth step leaves the next phase */
-#define QPSK_STEP_QUAD(SA_LO, SA_HI, SB_LO, SB_HI, RD1, RD2, QOFF, P4, L1, L2, L3, L4)                          \
-    QPSK_HEAD_DEFERRED("v140", "1" L1, "2" L1)                                                        \
-    QPSK_BODY("v140", "v141", SA_LO, QPSK_WAIT1, RD1, "")                                             \
-    QPSK_HEAD_DEFERRED("v141", "1" L2, "2" L2)                                                        \
-    QPSK_BODY("v141", "v142", SA_HI, "", "", "")                                                      \
-    QPSK_HEAD_DEFERRED("v142", "1" L3, "2" L3)                                                        \
-    QPSK_BODY("v142", "v143", SB_LO, QPSK_WAIT0, RD2, "")                                             \
-    QPSK_HEAD_DEFERRED("v143", "1" L4, "2" L4)                                                        \
-    QPSK_BODY("v143", P4, SB_HI, "", "", QPSK_QW(QOFF))
+#define QPSK_STEP_QUAD_(HD, BD, SA_LO, SA_HI, SB_LO, SB_HI, RD1, RD2, QOFF, P4, L1, L2, L3, L4)                \
+    HD("v140", "1" L1, "2" L1)                                                                        \
+    BD("v140", "v141", SA_LO, QPSK_WAIT1, RD1, "")                                                    \
+    HD("v141", "1" L2, "2" L2)                                                                        \
+    BD("v141", "v142", SA_HI, "", "", "")                                                             \
+    HD("v142", "1" L3, "2" L3)                                                                        \
+    BD("v142", "v143", SB_LO, QPSK_WAIT0, RD2, "")                                                    \
+    HD("v143", "1" L4, "2" L4)                                                                        \
+    BD("v143", P4, SB_HI, "", "", QPSK_QW(QOFF))
+#define QPSK_STEP_QUAD(...) QPSK_STEP_QUAD_(QPSK_HEAD_DEFERRED, QPSK_BODY, __VA_ARGS__)
 
 /*
  * Runs up to `groups` groups of COSTAS_ASM_GROUP steps starting at LDS addresses d_addr (symbols, 8 bytes each,
@@ -214,7 +285,7 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
 {
     unsigned long long flags, tmp;
     ign = uniform64(ign);
-    const double magic = 0x1.8p52, c3 = -0x1.6c087e89a359dp-10, s2 = 0x1.1107605230bc4p-7;
+    const double c3 = -0x1.6c087e89a359dp-10, s2 = 0x1.1107605230bc4p-7;
     double beal;                 /* (beta, alpha) as one VGPR pair for the packed multiply by d */
     {
         const float2 ba = make_float2(beta, alpha);
@@ -281,8 +352,8 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
         "s_waitcnt lgkmcnt(0)"
         : [p] "+v"(phase), [f] "+v"(freq), [da] "+v"(d_addr), [za] "+v"(z_addr), [ng] "+s"(groups),
           [fl] "=&s"(flags), [tm] "=&s"(tmp)
-        : [magic] "v"(magic), [c3] "v"(c3), [s2] "v"(s2), [fmax] "v"(max_freq), [beal] "v"(beal),
-          [k2pi] "s"(0x1.45F306DC9C883p-1), [hpi] "s"(0x1.921FB54442D18p0), [c4] "s"(0x1.99343027bf8c3p-16),
+        : [c3] "v"(c3), [s2] "v"(s2), [fmax] "v"(max_freq), [beal] "v"(beal),
+          [k2pi] "s"(0x1.45F306DC9C883p-1), [nhpi] "s"(-0x1.921FB54442D18p0), [c4] "s"(0x1.99343027bf8c3p-16),
           [s3] "s"(-0x1.994eb3774cf24p-13), [c2] "s"(0x1.55553e1068f19p-5), [s1] "s"(-0x1.555545995a603p-3),
           [c1] "s"(-0x1.ffffffd0c621cp-2), [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu), [ign] "s"(ign)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
@@ -327,6 +398,99 @@ __device__ __forceinline__ unsigned costas_asm_run(float &phase, float &freq, un
 #define QPSK_DA "v132"
 #define QPSK_ZA "v134"
 #define QPSK_RDN "ds_read_b128 v[120:123], v124\n\t"
+/* where the group loop's head sits relative to the 64-byte lines, per stream (tools/ubench_step.py --align) */
+#define QPSK_RING_ALIGN_1 ".p2align 6\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n"
+#define QPSK_RING_ALIGN_P ".p2align 6\n\ts_nop 0\n\ts_nop 0\n"
+#define QPSK_RING_TEXT(HC, HD, BD, WH, INIT, ALIGN)                                                                           \
+    "v_mov_b32 v128, 0x54442d18\n\t"        /* 2*pi = 0x401921FB54442D18 */                                            \
+    "v_mov_b32 v127, 0x401921fb\n\t" INIT                                                                                   \
+    "s_and_b32 %[t0], %[k], 7\n\t"                                                                                     \
+    "s_lshl_b32 %[t0], %[t0], 7\n\t"                                                                                   \
+    "v_add_u32_e32 v132, %[t0], %[db]\n\t"                                                                             \
+    "ds_read_b128 v[120:123], v132\n\t"                                                                                \
+    "s_mov_b64 %[fl], 0\n\t"                                                                                           \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                           \
+    /* the group loop's head 12 bytes behind a 64-byte boundary: a lone wave is limited by instruction fetch (header), and where \
+     * the 8-byte instructions of the 16-step body fall relative to the 32-byte fetch lines is worth 4 % -- 157.2 cycles \
+     * per step at this offset, 160.9 as the compiler placed it, 163.4 at the worst (tools/ubench_step.py --align,     \
+     * profiles/r03_step_cost.txt; re-measure after any edit of the stream) */                                         \
+    ALIGN                                                                                                              \
+    "2:\n\t"                                                                                                           \
+    /* ring addresses of group k and of group k + 1's first pair; the producer counter */                              \
+    "s_and_b32 %[t0], %[k], 7\n\t"                                                                                     \
+    "s_lshl_b32 %[t1], %[t0], 7\n\t"                                                                                   \
+    "v_add_u32_e32 v132, %[t1], %[db]\n\t"                                                                             \
+    "s_lshl_b32 %[t1], %[t0], 6\n\t"                                                                                   \
+    "v_add_u32_e32 v134, %[t1], %[zb]\n\t"                                                                             \
+    "s_add_u32 %[t0], %[k], 1\n\t"                                                                                     \
+    "s_and_b32 %[t0], %[t0], 7\n\t"                                                                                    \
+    "s_lshl_b32 %[t0], %[t0], 7\n\t"                                                                                   \
+    "v_add_u32_e32 v124, %[t0], %[db]\n\t"                                                                             \
+    "ds_read_b32 v125, %[ra]\n\t"                                                                                      \
+    "v_mov_b32 v130, %[p]\n\t"                                                                                         \
+    "v_mov_b32 v131, %[f]\n\t"                                                                                         \
+    "v_mov_b32 v118, %[f]\n\t"            /* the frequency accumulates in place (v_fmac) */                            \
+    "v_mov_b32 v126, 0x7f800000\n\t"                                                                                   \
+    "v_mov_b32 v140, %[p]\n\t"                                                                                         \
+    /* steps 0..3; outstanding in front of the first pair's use: the last group's record write and the counter read */ \
+    HC("v140")                                                                                            \
+    BD("v140", "v141", "v[120:121]", "s_waitcnt lgkmcnt(2)\n\t", QPSK_RDB(16), "")                                     \
+    HD("v141", "101", "201")                                                                                           \
+    BD("v141", "v142", "v[122:123]", "", "", "")                                                                       \
+    HD("v142", "102", "202")                                                                                           \
+    BD("v142", "v143", "v[136:137]", QPSK_WAIT0, QPSK_RDA(32), "")                                                     \
+    HD("v143", "103", "203")                                                                                           \
+    BD("v143", "v140", "v[138:139]", "", "", QPSK_QW(0))                                                               \
+    QPSK_STEP_QUAD_(HD, BD, "v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(48), QPSK_RDA(64), 16, "v140", "04", "05", "06", "07") \
+    QPSK_STEP_QUAD_(HD, BD, "v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(80), QPSK_RDA(96), 32, "v140", "08", "09", "10", "11") \
+    QPSK_STEP_QUAD_(HD, BD, "v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(112), QPSK_RDN, 48, "%[p]", "12", "13", "14", "15") \
+    QPSK_TAIL("%[p]", "%[f]", "116", "216")                                                                            \
+    "v_cmp_eq_f32_e64 %[tm], 0, v126\n\t"                                                                              \
+    "s_andn2_b64 %[tm], %[tm], %[ign]\n\t"   /* lanes the caller has looked at: nothing but +0.0 symbols ahead of them (below) */ \
+    "s_or_b64 %[fl], %[fl], %[tm]\n\t"                                                                                 \
+    "s_cmp_lg_u64 %[fl], 0\n\t"                                                                                        \
+    "s_cbranch_scc1 3f\n\t"                                                                                            \
+    "s_add_u32 %[k], %[k], 1\n\t"                                                                                      \
+    "s_and_b32 %[t0], %[k], 3\n\t"                                                                                     \
+    "s_cmp_lg_u32 %[t0], 0\n\t"                                                                                        \
+    "s_cbranch_scc1 2b\n\t"                 /* inside a chunk (kend is a multiple of 4) */                             \
+    /* chunk k / 4 - 1 is done: consumed = k / 4, by lane 0, behind the record writes */                               \
+    "s_lshr_b32 %[t0], %[k], 2\n\t"                                                                                    \
+    "v_mov_b32 v104, %[t0]\n\t"                                                                                        \
+    "s_mov_b64 %[ex], exec\n\t"                                                                                        \
+    "s_mov_b64 exec, 1\n\t"                                                                                            \
+    "ds_write_b32 %[ca], v104\n\t"                                                                                     \
+    "s_mov_b64 exec, %[ex]\n\t"                                                                                        \
+    "s_cmp_ge_u32 %[k], %[ke]\n\t"                                                                                     \
+    "s_cbranch_scc1 4f\n\t"                                                                                            \
+    /* next chunk there?  ready[] >= k / 4 + 1 in every lane, as read at the start of the group just done */           \
+    "v_cmp_le_i32_e64 %[tm], v125, %[t0]\n\t"                                                                          \
+    "s_cmp_lg_u64 %[tm], 0\n\t"                                                                                        \
+    "s_cbranch_scc0 2b\n\t"                                                                                            \
+    "s_branch 4f\n"                                                                                                    \
+    "3:\n\t"                                                                                                           \
+    "v_mov_b32 %[p], v130\n\t"                                                                                         \
+    "v_mov_b32 %[f], v131\n\t"                                                                                         \
+    "s_branch 4f\n"                                                                                                    \
+    WH("v141", "101", "201")                                                                               \
+    WH("v142", "102", "202")                                                                               \
+    WH("v143", "103", "203")                                                                               \
+    WH("v140", "104", "204")                                                                               \
+    WH("v141", "105", "205")                                                                               \
+    WH("v142", "106", "206")                                                                               \
+    WH("v143", "107", "207")                                                                               \
+    WH("v140", "108", "208")                                                                               \
+    WH("v141", "109", "209")                                                                               \
+    WH("v142", "110", "210")                                                                               \
+    WH("v143", "111", "211")                                                                               \
+    WH("v140", "112", "212")                                                                               \
+    WH("v141", "113", "213")                                                                               \
+    WH("v142", "114", "214")                                                                               \
+    WH("v143", "115", "215")                                                                               \
+    QPSK_WRAP_TAIL("%[p]", "116", "216")                                                                               \
+    "4:\n\t"                                                                                                           \
+    "s_waitcnt lgkmcnt(0)"
+
 __device__ __forceinline__ void costas_asm_run_ring(float &phase, float &freq, unsigned d_base, unsigned z_base,
                                                     unsigned ready_addr, unsigned consumed_addr, unsigned &k, unsigned kend,
                                                     float alpha, float beta, float min_freq, float max_freq,
@@ -336,108 +500,63 @@ __device__ __forceinline__ void costas_asm_run_ring(float &phase, float &freq, u
     ign = uniform64(ign);
     kend = __builtin_amdgcn_readfirstlane(kend);
     unsigned t0, t1;
-    const double magic = 0x1.8p52, c3 = -0x1.6c087e89a359dp-10, s2 = 0x1.1107605230bc4p-7;
+    const double c3 = -0x1.6c087e89a359dp-10, s2 = 0x1.1107605230bc4p-7;
     double beal;
     {
         const float2 ba = make_float2(beta, alpha);
         __builtin_memcpy(&beal, &ba, 8);
     }
     asm volatile(
-        "v_mov_b32 v128, 0x54442d18\n\t"        /* 2*pi = 0x401921FB54442D18 */
-        "v_mov_b32 v127, 0x401921fb\n\t"
-        "s_and_b32 %[t0], %[k], 7\n\t"
-        "s_lshl_b32 %[t0], %[t0], 7\n\t"
-        "v_add_u32_e32 v132, %[t0], %[db]\n\t"
-        "ds_read_b128 v[120:123], v132\n\t"
-        "s_mov_b64 %[fl], 0\n\t"
-        "s_waitcnt lgkmcnt(0)\n"
-        /* the group loop's head 12 bytes behind a 64-byte boundary: a lone wave is limited by instruction fetch (header), and where
-         * the 8-byte instructions of the 16-step body fall relative to the 32-byte fetch lines is worth 4 % -- 157.2 cycles
-         * per step at this offset, 160.9 as the compiler placed it, 163.4 at the worst (tools/ubench_step.py --align,
-         * profiles/r03_step_cost.txt; re-measure after any edit of the stream) */
-        ".p2align 6\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n"
-        "2:\n\t"
-        /* ring addresses of group k and of group k + 1's first pair; the producer counter */
-        "s_and_b32 %[t0], %[k], 7\n\t"
-        "s_lshl_b32 %[t1], %[t0], 7\n\t"
-        "v_add_u32_e32 v132, %[t1], %[db]\n\t"
-        "s_lshl_b32 %[t1], %[t0], 6\n\t"
-        "v_add_u32_e32 v134, %[t1], %[zb]\n\t"
-        "s_add_u32 %[t0], %[k], 1\n\t"
-        "s_and_b32 %[t0], %[t0], 7\n\t"
-        "s_lshl_b32 %[t0], %[t0], 7\n\t"
-        "v_add_u32_e32 v124, %[t0], %[db]\n\t"
-        "ds_read_b32 v125, %[ra]\n\t"
-        "v_mov_b32 v130, %[p]\n\t"
-        "v_mov_b32 v131, %[f]\n\t"
-        "v_mov_b32 v118, %[f]\n\t"            /* the frequency accumulates in place (v_fmac) */
-        "v_mov_b32 v126, 0x7f800000\n\t"
-        "v_mov_b32 v140, %[p]\n\t"
-        /* steps 0..3; outstanding in front of the first pair's use: the last group's record write and the counter read */
-        QPSK_HEAD_CHAIN("v140")
-        QPSK_BODY("v140", "v141", "v[120:121]", "s_waitcnt lgkmcnt(2)\n\t", QPSK_RDB(16), "")
-        QPSK_HEAD_DEFERRED("v141", "101", "201")
-        QPSK_BODY("v141", "v142", "v[122:123]", "", "", "")
-        QPSK_HEAD_DEFERRED("v142", "102", "202")
-        QPSK_BODY("v142", "v143", "v[136:137]", QPSK_WAIT0, QPSK_RDA(32), "")
-        QPSK_HEAD_DEFERRED("v143", "103", "203")
-        QPSK_BODY("v143", "v140", "v[138:139]", "", "", QPSK_QW(0))
-        QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(48), QPSK_RDA(64), 16, "v140", "04", "05", "06", "07")
-        QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(80), QPSK_RDA(96), 32, "v140", "08", "09", "10", "11")
-        QPSK_STEP_QUAD("v[120:121]", "v[122:123]", "v[136:137]", "v[138:139]", QPSK_RDB(112), QPSK_RDN, 48, "%[p]", "12", "13", "14", "15")
-        QPSK_TAIL("%[p]", "%[f]", "116", "216")
-        "v_cmp_eq_f32_e64 %[tm], 0, v126\n\t"
-        "s_andn2_b64 %[tm], %[tm], %[ign]\n\t"   /* lanes the caller has looked at: nothing but +0.0 symbols ahead of them (below) */
-        "s_or_b64 %[fl], %[fl], %[tm]\n\t"
-        "s_cmp_lg_u64 %[fl], 0\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "s_add_u32 %[k], %[k], 1\n\t"
-        "s_and_b32 %[t0], %[k], 3\n\t"
-        "s_cmp_lg_u32 %[t0], 0\n\t"
-        "s_cbranch_scc1 2b\n\t"                 /* inside a chunk (kend is a multiple of 4) */
-        /* chunk k / 4 - 1 is done: consumed = k / 4, by lane 0, behind the record writes */
-        "s_lshr_b32 %[t0], %[k], 2\n\t"
-        "v_mov_b32 v104, %[t0]\n\t"
-        "s_mov_b64 %[ex], exec\n\t"
-        "s_mov_b64 exec, 1\n\t"
-        "ds_write_b32 %[ca], v104\n\t"
-        "s_mov_b64 exec, %[ex]\n\t"
-        "s_cmp_ge_u32 %[k], %[ke]\n\t"
-        "s_cbranch_scc1 4f\n\t"
-        /* next chunk there?  ready[] >= k / 4 + 1 in every lane, as read at the start of the group just done */
-        "v_cmp_le_i32_e64 %[tm], v125, %[t0]\n\t"
-        "s_cmp_lg_u64 %[tm], 0\n\t"
-        "s_cbranch_scc0 2b\n\t"
-        "s_branch 4f\n"
-        "3:\n\t"
-        "v_mov_b32 %[p], v130\n\t"
-        "v_mov_b32 %[f], v131\n\t"
-        "s_branch 4f\n"
-        QPSK_WRAP_HEAD("v141", "101", "201")
-        QPSK_WRAP_HEAD("v142", "102", "202")
-        QPSK_WRAP_HEAD("v143", "103", "203")
-        QPSK_WRAP_HEAD("v140", "104", "204")
-        QPSK_WRAP_HEAD("v141", "105", "205")
-        QPSK_WRAP_HEAD("v142", "106", "206")
-        QPSK_WRAP_HEAD("v143", "107", "207")
-        QPSK_WRAP_HEAD("v140", "108", "208")
-        QPSK_WRAP_HEAD("v141", "109", "209")
-        QPSK_WRAP_HEAD("v142", "110", "210")
-        QPSK_WRAP_HEAD("v143", "111", "211")
-        QPSK_WRAP_HEAD("v140", "112", "212")
-        QPSK_WRAP_HEAD("v141", "113", "213")
-        QPSK_WRAP_HEAD("v142", "114", "214")
-        QPSK_WRAP_HEAD("v143", "115", "215")
-        QPSK_WRAP_TAIL("%[p]", "116", "216")
-        "4:\n\t"
-        "s_waitcnt lgkmcnt(0)"
+        QPSK_RING_TEXT(QPSK_HEAD_CHAIN, QPSK_HEAD_DEFERRED, QPSK_BODY, QPSK_WRAP_HEAD, "", QPSK_RING_ALIGN_1)
         : [p] "+v"(phase), [f] "+v"(freq), [k] "+s"(k), [fl] "=&s"(flags), [tm] "=&s"(tmp), [ex] "=&s"(ex),
           [t0] "=&s"(t0), [t1] "=&s"(t1)
         : [db] "v"(d_base), [zb] "v"(z_base), [ra] "v"(ready_addr), [ca] "v"(consumed_addr), [ke] "s"(kend),
-          [magic] "v"(magic), [c3] "v"(c3), [s2] "v"(s2), [fmax] "v"(max_freq), [beal] "v"(beal),
-          [k2pi] "s"(0x1.45F306DC9C883p-1), [hpi] "s"(0x1.921FB54442D18p0), [c4] "s"(0x1.99343027bf8c3p-16),
+          [c3] "v"(c3), [s2] "v"(s2), [fmax] "v"(max_freq), [beal] "v"(beal),
+          [k2pi] "s"(0x1.45F306DC9C883p-1), [nhpi] "s"(-0x1.921FB54442D18p0), [c4] "s"(0x1.99343027bf8c3p-16),
           [s3] "s"(-0x1.994eb3774cf24p-13), [c2] "s"(0x1.55553e1068f19p-5), [s1] "s"(-0x1.555545995a603p-3),
           [c1] "s"(-0x1.ffffffd0c621cp-2), [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu), [ign] "s"(ign)
+        : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+          "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
+          "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135",
+          "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143");
+    flags_out = flags;
+}
+
+/*
+ * The paired-lane form of the ring stream (QPSK_BODY_P): lanes 2f and 2f + 1 both carry loop f -- the same phase, frequency,
+ * gains, ring addresses (two lanes read one address: a broadcast; both write the same records to the same address) -- and
+ * `odd` tells a lane which of the two it is.  Everything else as costas_asm_run_ring.  For workgroups whose loops fill at
+ * most half the wave (rx_lean_kernel up to 16 frames per workgroup: BASELINE config 2).
+ */
+__device__ __forceinline__ void costas_asm_run_ring_pair(float &phase, float &freq, unsigned d_base, unsigned z_base,
+                                                         unsigned ready_addr, unsigned consumed_addr, unsigned &k, unsigned kend,
+                                                         float alpha, float beta, float min_freq, float max_freq, bool odd,
+                                                         unsigned long long &flags_out, unsigned long long ign = 0ull)
+{
+    unsigned long long flags, tmp, ex;
+    ign = uniform64(ign);
+    kend = __builtin_amdgcn_readfirstlane(kend);
+    unsigned t0, t1;
+    /* per-lane coefficients: the cosine's in the even lane, the sine's in the odd one (QPSK_BODY_P) */
+    const double ka = odd ? 0.0 : 0x1.99343027bf8c3p-16, kb = odd ? -0x1.994eb3774cf24p-13 : -0x1.6c087e89a359dp-10;
+    const double kc = odd ? 0x1.1107605230bc4p-7 : 0x1.55553e1068f19p-5, kd = odd ? -0x1.555545995a603p-3 : -0x1.ffffffd0c621cp-2;
+    const double km = odd ? 1.0 : 0.0, kj = odd ? -0.0 : 1.0;
+    const float sg = odd ? -1.0f : 1.0f;
+    double beal;
+    {
+        const float2 ba = make_float2(beta, alpha);
+        __builtin_memcpy(&beal, &ba, 8);
+    }
+    asm volatile(
+        /* the first step's zero test looks at the T of "the step before": anything but a zero */
+        QPSK_RING_TEXT(QPSK_HEAD_CHAIN_P, QPSK_HEAD_DEFERRED_P, QPSK_BODY_P, QPSK_WRAP_HEAD_P, "v_mov_b32 v114, 1.0\n\tv_mov_b32 v115, 1.0\n\t", QPSK_RING_ALIGN_P)
+        : [p] "+v"(phase), [f] "+v"(freq), [k] "+s"(k), [fl] "=&s"(flags), [tm] "=&s"(tmp), [ex] "=&s"(ex),
+          [t0] "=&s"(t0), [t1] "=&s"(t1)
+        : [db] "v"(d_base), [zb] "v"(z_base), [ra] "v"(ready_addr), [ca] "v"(consumed_addr), [ke] "s"(kend),
+          [ka] "v"(ka), [kb] "v"(kb), [kc] "v"(kc), [kd] "v"(kd), [km] "v"(km), [kj] "v"(kj), [sg] "v"(sg),
+          [fmax] "v"(max_freq), [beal] "v"(beal),
+          [k2pi] "s"(0x1.45F306DC9C883p-1), [nhpi] "s"(-0x1.921FB54442D18p0),
+          [fmin] "s"(min_freq), [tau] "s"(TAU_F), [absm] "s"(0x7fffffffu), [ign] "s"(ign)
         : "vcc", "scc", "memory", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
           "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",
           "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135",

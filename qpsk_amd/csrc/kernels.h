@@ -38,6 +38,8 @@ struct FusedArgs {
                                a window of its own, so a two-unit FIR wave's DMAs run a whole unit ahead (fir_lean_loop2_dma2w) */
     int lean_dma;           /* rx_lean_kernel: 1 = FIR waves whose frames all have an even decimation offset stage their windows by LDS-DMA
                                (fir_lean_asm.h, the _dma loops); 0 = always through registers.  Same bits either way ("QPSK_LEAN_DMA") */
+    int lean_pair;          /* rx_lean_kernel: the serial wave runs every loop in TWO lanes that share the step's sin/cos polynomial chains
+                               (costas_asm.h, QPSK_BODY_P): 1 = in workgroups of up to 16 frames, 2 = up to 32, 3 = up to 24 (the library's rule), 0 = never; launch_rx_lean turns the wish into 0 / 1.  Same bits ("QPSK_LEAN_PAIR") */
     int dbg;                /* layout variants of the pipeline kernel, all bit-exact (qpsk_ctx_set_tuning "QPSK_PIPE_DBG"):
                                4 no spare waves, 8 C++ Costas step, 16 serial wave chunk by chunk (no stream across the ring hand-overs), 64 FIR waves that share a SIMD keep their hardware order (16-frame kernel), 128 one lane mapping for all FIR waves (the plain
                                layout).  Measurement build only (-DQPSK_PIPE_PROFILE; masked off by api.cpp otherwise):

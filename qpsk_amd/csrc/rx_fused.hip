@@ -195,8 +195,14 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
      * round: this wave 1, the FIR wave beside it 3 [measured: 0.335 -> 0.294 ms at 8192 frames] */
     if (a.share_simd0 != ((a.dbg & 512) != 0)) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(3);
-    const int g = lane / nbw, b = lane - g * nbw;
-    const bool active = lane < G * nbw && f0 + g < a.nframes;
+    /* a.lean_pair (rx_lean_kernel, one loop per frame, at most 32 frames per workgroup): lanes 2g and 2g + 1 both carry frame g's loop
+     * and share the two polynomial chains of its step between them (costas_asm.h, costas_asm_run_ring_pair); wherever the instruction
+     * stream is not running the two lanes simply do the same thing */
+    const bool pair = a.lean_pair != 0;
+    const bool odd = pair && (lane & 1);
+    const int g = pair ? lane >> 1 : lane / nbw, b = pair ? 0 : lane - g * nbw;
+    const bool inwg = pair ? lane < 2 * G : lane < G * nbw;
+    const bool active = inwg && f0 + g < a.nframes;
     Loop st = {0.0f, 0.0f};
     LoopGains lg = {0.0f, 0.0f, a.min_freq, a.max_freq};
     if (active) {
@@ -208,10 +214,10 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
         }
     }
     /* the FIR wave that feeds this lane: 4 frames each; in the mixed workgroup frames 12..15 come two per wave */
-    const int gl = lane < G * nbw ? g : 0;
+    const int gl = inwg ? g : 0;
     const int gw = a.mixed == 2 ? gl / 2 : a.mixed == 1 && gl >= 12 ? 3 + (gl - 12) / 2 : gl / FWV;
-    const float2 *dl = dring + (size_t)(lane < G * nbw ? g : 0) * DSTRIDE;
-    float *zl = zring + (size_t)lane * ZSTRIDE;   /* this lane's records: the phase each symbol's step started from */
+    const float2 *dl = dring + (size_t)gl * DSTRIDE;
+    float *zl = zring + (size_t)(pair ? gl : lane) * ZSTRIDE;   /* this lane's records: the phase each symbol's step started from */
     /* one median-of-3 instead of two compare/select pairs when the clamp is the usual min < 0 < max */
     const bool fast_clamp = a.min_freq < 0.0f && a.max_freq > 0.0f;
     float ph = st.phase, fr = st.freq;
@@ -307,7 +313,10 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
                         rp_tick(rp_out);
                         if (rp_calls++ == 0) rp_rt1 = rp_real();
 #endif
-                        costas_asm_run_ring(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kstop, al, be, fmin_, fmax_, fl, ign);
+                        if (pair)
+                            costas_asm_run_ring_pair(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kstop, al, be, fmin_, fmax_, odd, fl, ign);
+                        else
+                            costas_asm_run_ring(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kstop, al, be, fmin_, fmax_, fl, ign);
                         ran = true;
 #ifdef QPSK_PIPE_PROFILE
                         rp_tick(rp_in);
@@ -437,7 +446,7 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
                rp_in / nchunks / S, rp_out / nchunks, (double)(rp_rt1 - rp_rt0) * 0.01, (double)(rp_rt2 - rp_rt1) * 0.01);
 #endif
     st.phase = ph; st.freq = fr;
-    if (active && ok) {
+    if (active && ok && !odd) {
         const size_t o = (size_t)(f0 + g) * nbw + b;
         if (a.freq) a.freq[o] = st.freq;
         if (a.phase) a.phase[o] = st.phase;
@@ -1432,6 +1441,7 @@ int launch_rx_pipe2(const FusedArgs &a0, int G, unsigned long long layout, int *
         pipe2_lds_bytes(G, nwin, a.nbw) > (size_t)MAX_LDS_BYTES)
         return (int)hipErrorInvalidValue;
     a.G = G;
+    a.lean_pair = 0;                                      /* one lane per loop: the paired stream is rx_lean_kernel's */
     a.mixed = 2;                                          /* the serial wave's lane for frame g waits on ready[g / 2] */
     a.share_simd0 = ((layout >> 16) & 15) != 0 || ((layout >> 32) & 15) != 0;   /* hardware waves 4, 8 */
     const int blocks = (a.nframes + G - 1) / G;
@@ -1809,6 +1819,11 @@ int launch_rx_lean(const FusedArgs &a0, int G, unsigned long long layout, int *s
     /* a window per UNIT where the LDS has the room (up to 16 frames per workgroup; a.lean_twowin comes in as the caller's wish) */
     a.lean_twowin = a.lean_twowin && a.lean_dma && units > nwin && lean_lds_bytes(G, units) <= (size_t)MAX_LDS_BYTES;
     if (a.lean_twowin) nwin = units;
+    /* two lanes of the serial wave per loop (costas_wave): a.lean_pair comes in as the caller's wish: 1 = up to 16 frames per workgroup,
+     * 2 = wherever the wave has the lanes, 3 = the library's rule: up to 24 frames per workgroup.  [Measured in steady state,
+     * profiles/r06_step_cost.txt: 4096 frames 0.1511-0.1520 -> 0.1488-0.1500 ms, 6144 frames 0.2113 -> 0.2055, 8192 frames (32 per
+     * workgroup, every lane of the wave busy, the board at its power limit) 0.2531 -> 0.2541-0.2545: not there] */
+    a.lean_pair = (a.lean_pair == 2 && 2 * G <= 64) || (a.lean_pair == 1 && G <= 16) || (a.lean_pair == 3 && G <= 24);
     size_t lds = lean_lds_bytes(G, nwin);
     if (a.est_tw) {
         /* the FFT timing estimate inside the launch: at least eight hardware waves share the workgroup's frames (waves without a unit
@@ -1851,6 +1866,7 @@ int pipe_max_nf(void) { return GeomNarrow::MAX_NF; }
 int launch_rx_fused_pipe(const FusedArgs &a0, int NF, int *status, hipStream_t s)
 {
     FusedArgs a = a0;
+    a.lean_pair = 0;
     /* the full narrow workgroup runs with two lane mappings (see the kernel): no SIMD carries two four-frame
      * units, every FIR wave has slack and the kernel follows the loop.  QPSK_PIPE_DBG bit 7 = the plain layout
      * (4 FIR waves + 1 spare) for A/B runs */
@@ -1876,9 +1892,11 @@ int launch_rx_fused_pipe(const FusedArgs &a0, int NF, int *status, hipStream_t s
     return (int)e;
 }
 
-int launch_costas_pipe(const FusedArgs &a, int NF, int *status, hipStream_t s)
+int launch_costas_pipe(const FusedArgs &a0, int NF, int *status, hipStream_t s)
 {
     using GM = GeomNarrow;
+    FusedArgs a = a0;
+    a.lean_pair = 0;
     const int G = NF * GM::FWV;
     const int blocks = (a.nframes + G - 1) / G;
     const size_t lds = sizeof(Smem) + sizeof(float2) * (size_t)G * GM::DSTRIDE + sizeof(float) * (size_t)G * GM::ZSTRIDE;

@@ -165,6 +165,43 @@ QPSK_HD SinCosRaw sincos_raw_horner(float y)
     return o;
 }
 
+/*
+ * The form the serial wave's instruction stream evaluates since round 6 (costas_asm.h, QPSK_HEAD_CHAIN / QPSK_BODY / QPSK_BODY_P):
+ * n = rint(fl(x * 2/pi)) -- v_mul_f64 + v_rndne_f64, a 4-byte encoding, instead of the magic-number fma + subtract -- and the reduced
+ * argument by a fused multiply-add IN PLACE on x (v_fmac_f64).  The product is rounded before the integer is taken, so this is not
+ * the same computation as sincos_raw_horner()'s; tools/check_device_sincos.cpp --stream shows the same n, hence the same floats, for
+ * every float with |x| <= 8 except -0 (n = -0 there and the reduced argument +0: the kernels keep a -0 phase away from the stream).
+ * The polynomial stages are sincos_raw_horner()'s; the paired-lane body evaluates them with per-lane coefficients:
+ *   cosine lane: M = fma(xr, 0, 1) = 1, r = fma(x2, c4, c3), A = x2 * M = x2, ..., C = fma(A, r, M)
+ *   sine lane:   M = fma(xr, 1, -0) = xr, r = fma(x2, 0, s3) = s3, A = x2 * M = x3, ..., S = fma(A, r, M)
+ * restated here stage by stage so that the host check covers exactly what the lanes execute.
+ */
+QPSK_HD SinCosRaw sincos_raw_stream(float y)
+{
+    const double x = (double)y;
+    const double t = x * 0x1.45F306DC9C883p-1;
+    const double nd = __builtin_rint(t);
+    const double xr = __builtin_fma(-0x1.921FB54442D18p0, nd, x);
+    const double x2 = xr * xr;
+    /* even lane */
+    const double mc = __builtin_fma(xr, 0.0, 1.0);
+    double rc = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+    const double ac = x2 * mc;
+    rc = __builtin_fma(x2, rc, 0x1.55553e1068f19p-5);
+    rc = __builtin_fma(x2, rc, -0x1.ffffffd0c621cp-2);
+    /* odd lane */
+    const double ms = __builtin_fma(xr, 1.0, -0.0);
+    double rs = __builtin_fma(x2, 0.0, -0x1.994eb3774cf24p-13);
+    const double as = x2 * ms;
+    rs = __builtin_fma(x2, rs, 0x1.1107605230bc4p-7);
+    rs = __builtin_fma(x2, rs, -0x1.555545995a603p-3);
+    SinCosRaw o;
+    o.c = (float)__builtin_fma(ac, rc, mc);
+    o.s = (float)__builtin_fma(as, rs, ms);
+    o.n = (unsigned)(long long)nd;
+    return o;
+}
+
 QPSK_HD SinCos sincos_from_raw(SinCosRaw r)
 {
     /* quadrant 0: (S, C)  1: (C, -S)  2: (-S, -C)  3: (-C, S) */

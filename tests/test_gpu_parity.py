@@ -405,6 +405,34 @@ def test_lean_kernel_window_staging_by_dma_and_through_registers(oracle, mode):
         assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz"))
 
 
+@pytest.mark.parametrize("F,pipe_g", [(4096, None), (8192, None), (1024, None), (3072, None), (1280, 10)])
+def test_lean_kernel_paired_serial_lanes(oracle, F, pipe_g):
+    """rx_lean_kernel's serial wave with ONE lane per loop and with TWO (round 6: lanes 2f, 2f + 1 share the step's sine / cosine polynomial
+    chains, costas_asm.h QPSK_BODY_P; QPSK_LEAN_PAIR 0 / 1 = up to 16 frames per workgroup / 2 = up to 32): the same bits, at 4-32 frames
+    per workgroup, on frames that send the stream through every one of its exits -- clean modem frames (a 2 pi wrap every 48 steps or
+    so), noise (wraps at random), silent frames and silent stretches inside frames (the zero test trips, lanes are excused), real-only
+    frames (T.x or T.y exactly zero whenever the phase is: the C++ step takes the group), tiny and large levels."""
+    import torch
+    fs, rs, L = 19200.0, 2400.0, 1536
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=50.0, base_seed=61, noise=0.03)
+    x[1::16] = random_frames(len(x[1::16]), L, seed=62)
+    x[5::64] = 0.0
+    x[7::32, 300:900] = 0.0
+    x[9::32, :, 1] = 0.0
+    x[11::64] *= 1e-18
+    x[13::64] *= 300.0
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=6, threads=min(16, os.cpu_count() or 1))
+    xd = torch.from_numpy(x).cuda()
+    m.tune(pipe_g=pipe_g)
+    for pair in (0, 1, 2, None):
+        m.tune(lean_pair=pair)
+        got = m.rx_batch(xd)
+        m.sync()
+        assert m.last_kernel() == "rx_lean_kernel", m.last_kernel()
+        assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz"))
+
+
 def test_full_size_config2_bench_stimulus_every_frame(oracle):
     """the batch bench.py TIMES: config 2 at full size built by the library's own transmit chain (bench.tx_frames_gpu, the default
     --stimulus tx, rank 0's seed) -- EVERY one of the 4096 frames against the oracle, bit for bit (the oracle's fixed-offset path runs
