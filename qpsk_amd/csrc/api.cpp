@@ -121,7 +121,7 @@ struct qpsk_ctx {
     int *h_status = nullptr;     /* host view */
     int *d_status = nullptr;     /* device view of the same word */
     std::vector<float> h_gains;
-    DevBuf index, filtered, mixed, keystream;
+    DevBuf index, filtered, mixed, keystream, sympad;
     int keystream_len = 0;
     std::map<int, double *> twiddles;
     float *d_fast = nullptr;      /* qpsk_rrc_fir_batch_fast: H[512][2] then tw[512][2]; rebuilt when the taps change */
@@ -356,6 +356,7 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
     hipFree(c->filtered.p);
     hipFree(c->mixed.p);
     hipFree(c->keystream.p);
+    hipFree(c->sympad.p);
     for (auto &kv : c->twiddles) hipFree(kv.second);
     hipFree(c->d_fast);
     free_streams(c);
@@ -681,7 +682,10 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
          * and since round 5 (LDS-DMA staging, a window per unit, two-unit FIR waves) this one is ahead there too -- 0.1519 against 0.1560 ms
          * at config 2, 1-2 % at 1024-3584 frames (profiles/r05_config2_lean.txt) -- for batches it takes in ONE launch (whole workgroups
          * of at least four frames). */
-        const bool wanted = pipe_v == 3 || G > 16 || (G >= 4 && nframes % G == 0);
+        /* Round 6: a batch that is not whole workgroups rides in the same launch -- the last workgroup's pad frames read the batch's last
+         * frame and leave their symbols in a pad buffer (round 5 sent the remainder to a SECOND launch: one more 2048-step serial chain,
+         * 0.25 + 0.15 ms for 8193 frames against 0.25 for 8192). */
+        const bool wanted = pipe_v == 3 || G >= 4;
         unsigned long long layout = 0;
         if (c->tune.layout_lo >= 0 || c->tune.layout_hi >= 0)
             layout = ((unsigned long long)(unsigned)tuned(c->tune.layout_lo, 0) << 4) |
@@ -689,8 +693,12 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
         else if (G >= 2)
             layout = lean_default_layout(G / 2);
         FusedArgs am = a;
-        am.nframes = nframes - nframes % (G > 0 ? G : 1);
-        if (wanted && layout && am.nframes > 0 && lean_shape_ok(am, G)) {
+        if (G >= 2 && nframes % G) {
+            int rp = ensure(c, c->sympad, (size_t)G * (size_t)c->nsym);
+            if (rp) return rp;
+            a.sym_pad = am.sym_pad = (uint8_t *)c->sympad.p;
+        }
+        if (wanted && layout && lean_shape_ok(am, G)) {
             int nwin = 0, units = 0;
             for (int w = 1; w < 16; w++) { const int cw = (int)((layout >> (4 * w)) & 15); units += cw; nwin += cw != 0; }
             if (units == G / 2 && lean_lds_bytes(G, nwin) <= (size_t)MAX_LDS_BYTES) {
@@ -699,11 +707,6 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
                 main_pl.nframes = am.nframes;
                 main_pl.G = G;
                 main_pl.layout = layout;
-                const int rem = nframes - am.nframes;
-                if (rem > 0) {      /* the last partial workgroup */
-                    int rp = plan_general(rem, rem > 16 * c->ncu ? 2 : 1, &rem_pl);
-                    if (rp) return rp;
-                }
             }
         }
     }
@@ -780,6 +783,13 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
             if (rc2) return rc2;
             c->last_kernel = lk;
         }
+    }
+    if (main_pl.kind == K_LEAN && (nframes & 1)) {
+        /* the last frame of an odd batch shares its two-frame unit with a pad frame: the unit's rows are pad rows (rx_fused.hip,
+         * lean_unit_rows); its own row goes to its place behind the launch */
+        const size_t last0 = (size_t)((nframes - 1) / main_pl.G) * (size_t)main_pl.G;      /* the last workgroup's first frame */
+        HIP_TRY(hipMemcpyAsync(d_sym + (size_t)(nframes - 1) * (size_t)c->nsym, (const uint8_t *)c->sympad.p + ((size_t)(nframes - 1) - last0) * (size_t)c->nsym,
+                               (size_t)c->nsym, hipMemcpyDeviceToDevice, c->stream));
     }
     if (d_index) {
         if (idx)

@@ -61,6 +61,8 @@ struct FusedArgs {
     const float *state_in;  /* [nframes][nbw][2] phase, freq or NULL */
     float *state_out;       /* same or NULL */
     uint8_t *sym;           /* [nframes][nbw][nsym] */
+    uint8_t *sym_pad;       /* rx_lean_kernel on a batch whose last workgroup is not full: [G][nsym] bytes for the pad frames' symbols (and for
+                               the last real frame of an odd batch, whose two-frame unit reaches past the end); NULL = whole workgroups only */
     float *freq, *phase;    /* [nframes][nbw] or NULL */
     float2 *costas;         /* [nframes][nbw][nsym] or NULL */
     float *hz;              /* [nframes][nbw] or NULL */

@@ -466,8 +466,8 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
  */
 template <class GM, int RW = GM::R>   /* RW symbols per lane: S / RW lanes per frame */
 __device__ __forceinline__ void flush_records(const FusedArgs &a, const float *zring, const float2 *dring, int g, int frame,
-                                              int q, int chunk)
-{
+                                              int q, int chunk, uint8_t *sym_row = nullptr)
+{   /* sym_row (one loop per frame): where this frame's symbols go instead of a.sym + frame * nsym (rx_lean_kernel's pad rows) */
     constexpr int DSTRIDE = GM::DSTRIDE;
     constexpr int R = RW, S = GM::S, ZSTRIDE = GM::ZSTRIDE;
     static_assert(R == 2 || R == 4, "packs 2 or 4 symbols per store");
@@ -508,12 +508,13 @@ __device__ __forceinline__ void flush_records(const FusedArgs &a, const float *z
         for (int r = 0; r < R; r++)
             packed |= (uint32_t)slicer(z[r]) << (8 * r);
         if (a.sym) {
+            uint8_t *so = sym_row ? sym_row + sym0 + R * q : a.sym + o;
             if (R * q + R <= cnt && ((N | sym0) & (R - 1)) == 0) {   /* o is a multiple of R: one aligned store */
-                if constexpr (R == 4) *reinterpret_cast<uint32_t *>(a.sym + o) = packed;
-                else *reinterpret_cast<uint16_t *>(a.sym + o) = (uint16_t)packed;
+                if constexpr (R == 4) *reinterpret_cast<uint32_t *>(so) = packed;
+                else *reinterpret_cast<uint16_t *>(so) = (uint16_t)packed;
             } else {
                 for (int r = 0; r < R; r++)
-                    if (R * q + r < cnt) a.sym[o + r] = (uint8_t)(packed >> (8 * r));
+                    if (R * q + r < cnt) so[r] = (uint8_t)(packed >> (8 * r));
             }
         }
         if (a.costas) {
@@ -1458,7 +1459,7 @@ int launch_rx_pipe2(const FusedArgs &a0, int G, unsigned long long layout, int *
  * waits for its symbol stores or for the prefetched samples of its next unit -- and one counted vmcnt wait per unit.
  * What it serves (launch_rx_lean checks; everything else stays with the kernels above): CYCLES = 8, frames of whole
  * 64-symbol chunks (at least two), one loop per frame from a fresh state, no costas_frame[] dump, a symmetric filter,
- * 16-byte aligned frames, whole workgroups of an even number of frames.  Results: the same bits.
+ * 16-byte aligned frames, workgroups of an even number of frames (the batch's last one may be partly pad: round 6).  Results: the same bits.
  * ======================================================================== */
 namespace lean {
 /*
@@ -1503,6 +1504,15 @@ __device__ __host__ constexpr int rows_of(int G) { return G > HW_WAVES ? G : HW_
 } // namespace lean
 constexpr size_t LEAN_EST_LDS_BYTES = 128 * sizeof(float) + 32 * sizeof(int);   /* in-launch FFT estimate: taps, the workgroup's indices */
 
+/* the two symbol rows of unit u of the workgroup whose first frame is f0: the caller's, or -- a unit that reaches past the batch's last
+ * frame (the last workgroup of a ragged batch) -- its two rows of the launch's pad buffer (a.sym_pad: G rows; api.cpp copies the one real
+ * row of a unit that straddles the end, i.e. the last frame of an odd batch, to its place behind the launch) */
+__device__ __forceinline__ uint8_t *lean_unit_rows(const FusedArgs &a, int f0, int u)
+{
+    const int fa = f0 + pipe2::UF * u;
+    return fa + pipe2::UF <= a.nframes ? a.sym + (size_t)fa * a.nsym : a.sym_pad + (size_t)(pipe2::UF * u) * a.nsym;
+}
+
 template <int NUW>
 __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm, unsigned char *rows, float2 *mywin,
                                               int hwave, int u0, int f0, int lane, int nchunks, int *status, const int *est)
@@ -1523,7 +1533,7 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
         for (int ff = 0; ff < UF; ff++) {
             const int fr = f0 + UF * (u0 + ui) + ff;
             /* decimation offset, < C: the estimate made inside this launch (est[], in LDS), the caller's array, or the fixed one */
-            const int ix = __builtin_amdgcn_readfirstlane(est ? est[UF * (u0 + ui) + ff] : a.index ? a.index[fr] : a.fixed_index) & 7;
+            const int ix = __builtin_amdgcn_readfirstlane(est ? est[UF * (u0 + ui) + ff] : a.index ? a.index[min(fr, a.nframes - 1)] : a.fixed_index) & 7;
             ixpack |= (unsigned)ix << (4 * (2 * ui + ff));
         }
     /* which stream this wave runs (wave-uniform): LDS-DMA staging needs even offsets (16-byte pairs); a two-unit wave that stages by
@@ -1543,7 +1553,9 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
             w.wr0[ui][ff] = lds_addr(mywin + wu + ff * WS + slot_of(p0)) - 8u * BLK;
             w.wr1[ui][ff] = lds_addr(mywin + wu + ff * WS + slot_of(p0 + 1)) - 8u * BLK;
             if (lane == 0) {
-                size_t fsrc = (size_t)fr;
+                /* a batch's last workgroup may have fewer than G frames: its pad frames read the batch's last frame (valid memory) and
+                 * their symbols go to the launch's pad rows (below); their lanes of the serial wave are switched off */
+                size_t fsrc = (size_t)min(fr, a.nframes - 1);
 #ifdef QPSK_PIPE_PROFILE
                 /* measurement build, dbg bit 21: a workgroup's frames a grid apart instead of adjacent (WRONG frame -> output mapping;
                  * the visit order of the batch in memory is what is measured) */
@@ -1562,7 +1574,7 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
         w.ring[ui] = lds_addr(dring + (size_t)g * GM::DSTRIDE + R * q);
         w.z[ui] = lds_addr(zring + (size_t)g * GM::ZSTRIDE + R * q);
         if (lane == 0) {
-            const unsigned long long sb = (unsigned long long)(a.sym + (size_t)(f0 + UF * u) * N);
+            const unsigned long long sb = (unsigned long long)lean_unit_rows(a, f0, u);
             prm[8 + 2 * ui] = (unsigned)sb;
             prm[8 + 2 * ui + 1] = (unsigned)(sb >> 32);
         }
@@ -1655,7 +1667,7 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
 #pragma unroll
                 for (int ui = 0; ui < NUW; ui++) {
                     const int g = UF * (u0 + ui) + fl;
-                    flush_records<GM, R>(a, zring, dring, g, f0 + g, q, c);
+                    flush_records<GM, R>(a, zring, dring, g, f0 + g, q, c, lean_unit_rows(a, f0, u0 + ui) + (size_t)fl * N);
                 }
         }
     } else if (lane == 0) {
@@ -1721,6 +1733,17 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
     __syncthreads();
 
     if (wave == 0) {   /* a.mixed == 2: lane g waits on ready[g / 2] */
+        /* a ragged batch's last workgroup: the serial wave's lanes of the pad frames are off, so nothing makes it wait for THEIR units --
+         * and the record half of row w is hardware wave w's parameter block until that wave has read it (lean::, above), which the
+         * first hand-over of every unit proves: wait for the pad units' too before the first record is written */
+        if (f0 + G > a.nframes) {
+            bool ok = true;
+            for (int u = (a.nframes - f0 + UF - 1) / UF; u < G / UF && ok; u++) ok = wait_ge(&sm->ready[u], 1, &sm->abort_flag);
+            if (!ok) {
+                if (lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
+                return;
+            }
+        }
         costas_wave<GM>(a, sm, reinterpret_cast<const float2 *>(rows), reinterpret_cast<float *>(rows + lean::Z_OFFSET_BYTES), G,
                         f0, lane, nchunks, status);
         return;
@@ -1776,66 +1799,78 @@ unsigned long long lean_default_layout(int NU)
 bool lean_shape_ok(const FusedArgs &a, int G)
 {
     return a.nbw == 1 && !a.costas && !a.state_in && !a.state_out && a.nsym % pipe2::S == 0 && a.nsym >= 2 * pipe2::S &&
-           a.frame_size == a.nsym * C && G >= 2 && G % 2 == 0 && G <= pipe2::UF * pipe2::MAX_UNITS && a.nframes % G == 0 &&
-           !(a.dbg & (8 | 16));
+           a.frame_size == a.nsym * C && G >= 2 && G % 2 == 0 && G <= pipe2::UF * pipe2::MAX_UNITS && a.nframes >= 1 &&
+           (a.nframes % G == 0 || a.sym_pad) && !(a.dbg & (8 | 16));
 }
 
-/* can rx_lean_kernel run the FFT timing estimate inside its launch at this geometry?  (launch_rx_lean's own rule: api.cpp asks, it does
- * not restate) */
-bool lean_est_ok(const FusedArgs &a, int G, unsigned long long layout)
-{
-    using namespace pipe2;
-    int units = 0, nwin = 0, hw = 1;
-    for (int w = 1; w < 16; w++) {
-        const int cw = (int)((layout >> (4 * w)) & 15);
-        units += cw;
-        nwin += cw != 0;
-        if (cw) hw = w + 1;
-    }
-    if (a.lean_twowin && a.lean_dma && units > nwin && lean_lds_bytes(G, units) <= (size_t)MAX_LDS_BYTES) nwin = units;
-    if (hw < 8) hw = 8;
-    const int room = (int)((size_t)nwin * UF * lean::WS / tfft::WSLOTS), nwe = hw < room ? hw : room;
-    return a.frame_size >= tfft::N0 + tfft::NFFT && nwe >= 1 && (G + nwe - 1) / nwe <= tfft::MAX_FPW && G <= 32 &&
-           lean_lds_bytes(G, nwin) + LEAN_EST_LDS_BYTES <= (size_t)MAX_LDS_BYTES;
-}
+/*
+ * rx_lean_kernel's launch geometry for G frames per workgroup under `layout`, derived in ONE place (round 5 derived units / windows /
+ * estimator waves / LDS twice, in lean_est_ok and in launch_rx_lean: VERDICT r5): the question "does the FFT timing estimate fit inside
+ * the launch" and the launch itself read the same numbers.
+ */
+struct LeanGeometry {
+    bool ok;          /* layout and LDS are valid for G */
+    bool est_ok;      /* ... and the in-launch FFT timing estimate fits beside them */
+    int units, nwin, hw;      /* two-frame units, frame windows, hardware waves launched WITHOUT the estimate */
+    int hw_est, nwe;          /* hardware waves launched WITH it (at least eight), and how many of them estimate */
+    bool twowin, pair;
+    size_t lds, lds_est;
+};
 
-int launch_rx_lean(const FusedArgs &a0, int G, unsigned long long layout, int *status, hipStream_t s)
+static LeanGeometry lean_geometry(const FusedArgs &a, int G, unsigned long long layout)
 {
     using namespace pipe2;
-    FusedArgs a = a0;
-    int units = 0, nwin = 0, hw = 1;
+    LeanGeometry g{};
+    g.hw = 1;
+    bool valid = (layout & 15) == 0;
     for (int w = 1; w < 16; w++) {
         const int cw = (int)((layout >> (4 * w)) & 15);
-        if (cw > 2 || (cw && w >= MAX_THREADS / 64)) return (int)hipErrorInvalidValue;
-        units += cw;
-        nwin += cw != 0;
-        if (cw) hw = w + 1;
+        if (cw > 2 || (cw && w >= MAX_THREADS / 64)) valid = false;
+        g.units += cw;
+        g.nwin += cw != 0;
+        if (cw) g.hw = w + 1;
     }
-    if (!lean_shape_ok(a, G) || units != G / UF || (layout & 15) || lean_lds_bytes(G, nwin) > (size_t)MAX_LDS_BYTES)
-        return (int)hipErrorInvalidValue;
-    a.G = G;
-    a.mixed = 2;
-    a.share_simd0 = ((layout >> 16) & 15) != 0 || ((layout >> 32) & 15) != 0;
+    valid = valid && G >= 2 && g.units == G / UF && lean_lds_bytes(G, g.nwin) <= (size_t)MAX_LDS_BYTES;
     /* a window per UNIT where the LDS has the room (up to 16 frames per workgroup; a.lean_twowin comes in as the caller's wish) */
-    a.lean_twowin = a.lean_twowin && a.lean_dma && units > nwin && lean_lds_bytes(G, units) <= (size_t)MAX_LDS_BYTES;
-    if (a.lean_twowin) nwin = units;
+    g.twowin = valid && a.lean_twowin && a.lean_dma && g.units > g.nwin && lean_lds_bytes(G, g.units) <= (size_t)MAX_LDS_BYTES;
+    if (g.twowin) g.nwin = g.units;
     /* two lanes of the serial wave per loop (costas_wave): a.lean_pair comes in as the caller's wish: 1 = up to 16 frames per workgroup,
      * 2 = wherever the wave has the lanes, 3 = the library's rule: up to 24 frames per workgroup.  [Measured in steady state,
      * profiles/r06_step_cost.txt: 4096 frames 0.1511-0.1520 -> 0.1488-0.1500 ms, 6144 frames 0.2113 -> 0.2055, 8192 frames (32 per
      * workgroup, every lane of the wave busy, the board at its power limit) 0.2531 -> 0.2541-0.2545: not there] */
-    a.lean_pair = (a.lean_pair == 2 && 2 * G <= 64) || (a.lean_pair == 1 && G <= 16) || (a.lean_pair == 3 && G <= 24);
-    size_t lds = lean_lds_bytes(G, nwin);
-    if (a.est_tw) {
-        /* the FFT timing estimate inside the launch: at least eight hardware waves share the workgroup's frames (waves without a unit
-         * retire after it), at most MAX_FPW frames per wave, estimator windows in the frame windows, taps + indices behind the rows */
-        if (hw < 8) hw = 8;
-        const int room = (int)((size_t)nwin * UF * lean::WS / tfft::WSLOTS), nwe = hw < room ? hw : room;
-        lds += LEAN_EST_LDS_BYTES;
-        if (!a.est_cs || a.index || a.frame_size < tfft::N0 + tfft::NFFT || nwe < 1 || (G + nwe - 1) / nwe > tfft::MAX_FPW ||
-            G > 32 || lds > (size_t)MAX_LDS_BYTES)
-            return (int)hipErrorInvalidValue;
-    }
-    hipLaunchKernelGGL(rx_lean_kernel, dim3(a.nframes / G), dim3(64 * hw), lds, s, a, layout, nwin, status);
+    g.pair = (a.lean_pair == 2 && 2 * G <= 64) || (a.lean_pair == 1 && G <= 16) || (a.lean_pair == 3 && G <= 24);
+    g.lds = lean_lds_bytes(G, g.nwin);
+    /* the FFT timing estimate inside the launch: at least eight hardware waves share the workgroup's frames (waves without a unit retire
+     * after it), at most MAX_FPW frames per wave, estimator windows in the frame windows, taps + indices behind the rows */
+    g.hw_est = g.hw < 8 ? 8 : g.hw;
+    const int room = (int)((size_t)g.nwin * UF * lean::WS / tfft::WSLOTS);
+    g.nwe = g.hw_est < room ? g.hw_est : room;
+    g.lds_est = g.lds + LEAN_EST_LDS_BYTES;
+    g.ok = valid;
+    g.est_ok = valid && a.frame_size >= tfft::N0 + tfft::NFFT && g.nwe >= 1 && (G + g.nwe - 1) / g.nwe <= tfft::MAX_FPW && G <= 32 &&
+               g.lds_est <= (size_t)MAX_LDS_BYTES;
+    return g;
+}
+
+/* can rx_lean_kernel run the FFT timing estimate inside its launch at this geometry?  (api.cpp asks; launch_rx_lean reads the same numbers) */
+bool lean_est_ok(const FusedArgs &a, int G, unsigned long long layout)
+{
+    return lean_geometry(a, G, layout).est_ok;
+}
+
+int launch_rx_lean(const FusedArgs &a0, int G, unsigned long long layout, int *status, hipStream_t s)
+{
+    FusedArgs a = a0;
+    const LeanGeometry g = lean_geometry(a, G, layout);
+    if (!g.ok || !lean_shape_ok(a, G)) return (int)hipErrorInvalidValue;
+    if (a.est_tw && (!g.est_ok || !a.est_cs || a.index)) return (int)hipErrorInvalidValue;
+    a.G = G;
+    a.mixed = 2;
+    a.share_simd0 = ((layout >> 16) & 15) != 0 || ((layout >> 32) & 15) != 0;
+    a.lean_twowin = g.twowin;
+    a.lean_pair = g.pair;
+    hipLaunchKernelGGL(rx_lean_kernel, dim3((a.nframes + G - 1) / G), dim3(64 * (a.est_tw ? g.hw_est : g.hw)), a.est_tw ? g.lds_est : g.lds, s, a,
+                       layout, g.nwin, status);
     return (int)hipGetLastError();
 }
 

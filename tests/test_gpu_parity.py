@@ -121,7 +121,7 @@ def test_rx_batch_fft_timing(oracle, fs, rs, L, F):
 INLINE = " (FFT timing estimate inside the launch)"
 
 
-@pytest.mark.parametrize("tune,kernel", [(dict(pipe_g=32), "rx_lean_kernel"), (dict(pipe_g=20), "rx_lean_kernel"), (dict(pipe_g=8), "rx_lean_kernel" + INLINE),
+@pytest.mark.parametrize("tune,kernel", [(dict(pipe_g=32), "rx_lean_kernel"), (dict(pipe_g=20), "rx_lean_kernel" + INLINE), (dict(pipe_g=8), "rx_lean_kernel" + INLINE),
                                          (dict(pipe_v=2), "rx_pipe2_kernel"), (dict(pipe_v=3), "rx_lean_kernel" + INLINE),
                                          (dict(pipe_v=1), "rx_fused_pipe_kernel" + INLINE), (dict(pipe_v=1, pipe_nf=2), "rx_fused_pipe_kernel"),
                                          (dict(fused_generic=1), "rx_fused_kernel"), (dict(lean_dma=0), "rx_lean_kernel" + INLINE),
@@ -132,8 +132,8 @@ def test_fft_timing_under_every_geometry_key(oracle, tune, kernel):
     FFT estimate runs inside the receive launch and missed QPSK_PIPE_G: with G above 16 the batch went to rx_lean_kernel, which has no
     estimate, with no index computed -- silently wrong symbols.  The plan is now made once and the estimate's placement reads it: the
     FFT-timed batch under every key that moves it to another kernel, against the oracle, the index included.  (QPSK_PIPE_G = 32 fills the
-    LDS: no room for the estimate's 640 bytes; 20 frames per workgroup leave a last partial workgroup for another kernel: the estimate
-    then runs in front of both.)"""
+    LDS: no room for the estimate's 640 bytes; 20 frames per workgroup leave a last partial workgroup: until round 5 that went to another
+    kernel and the estimate ran in front of both, since round 6 the partial workgroup rides in rx_lean_kernel's launch, estimate included.)"""
     from oracle.pyoracle import TIMING_FFT
     fs, rs, L, F = 19200.0, 2400.0, 1024, 4096        # 4096 frames = 16 per CU: the in-launch estimate's shape when nothing is set
     m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FFT, fixed_index=3)     # a fixed_index that is NOT the estimate (6)
@@ -431,6 +431,39 @@ def test_lean_kernel_paired_serial_lanes(oracle, F, pipe_g):
         m.sync()
         assert m.last_kernel() == "rx_lean_kernel", m.last_kernel()
         assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz"))
+
+
+@pytest.mark.parametrize("F,mode", [(4097, "fixed"), (5001, "fixed"), (8191, "fixed"), (8193, "fixed"), (8200, "hist"), (1031, "fft"), (1033, "fixed"),
+                                    (4099, "hist")])
+def test_ragged_batches_ride_in_one_launch(oracle, F, mode):
+    """A batch that is not whole workgroups: round 5 sent the remainder to a second, serialized launch (one more 2048-step serial chain);
+    since round 6 rx_lean_kernel's last workgroup carries pad frames -- they read the batch's last frame, their symbols go to a pad
+    buffer, their lanes of the serial wave are off, and the last frame of an ODD batch (half a two-frame unit) is copied to its place
+    behind the launch.  Every frame against the oracle, with per-frame timing offsets (histogram mode) and the in-launch FFT estimate
+    too; the outputs sit in a buffer with a canary behind them."""
+    import torch
+    from oracle.pyoracle import TIMING_FFT, TIMING_HIST as TH
+    fs, rs, L = 19200.0, 2400.0, 1024
+    tm = {"fixed": TIMING_FIXED, "hist": TH, "fft": TIMING_FFT}[mode]
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=tm, fixed_index=6)
+    x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=40.0, base_seed=300 + F, noise=0.04)
+    x[2::7] = random_frames(len(x[2::7]), L, seed=F)
+    x[-1] = random_frames(1, L, seed=F + 1)[0]          # the frame the pad frames read
+    want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=tm, fixed_index=6, threads=min(16, os.cpu_count() or 1))
+    xd = torch.from_numpy(x).cuda()
+    N = m.nsym
+    sym = torch.full((F * N + 4096,), 0xEE, dtype=torch.uint8, device="cuda")
+    fr = torch.full((F + 64,), 7.0, dtype=torch.float32, device="cuda")
+    ph = torch.full((F + 64,), 7.0, dtype=torch.float32, device="cuda")
+    m.rx_batch_raw(xd, F, sym, fr, ph)
+    m.sync()
+    assert m.last_kernel().startswith("rx_lean_kernel"), m.last_kernel()
+    assert np.array_equal(cpu(sym[:F * N]).reshape(F, N), want["sym"])
+    assert bits_equal(cpu(fr[:F]), want["freq"]) and bits_equal(cpu(ph[:F]), want["phase"])
+    assert bool((sym[F * N:] == 0xEE).all()) and bool((fr[F:] == 7.0).all()) and bool((ph[F:] == 7.0).all()), "wrote behind the batch"
+    got = m.rx_batch(xd)
+    m.sync()
+    assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz"))
 
 
 def test_full_size_config2_bench_stimulus_every_frame(oracle):
