@@ -60,6 +60,17 @@ typedef complex double qpsk_dropin_cdouble;
 #ifndef NFFT
 #define NFFT 512                                                           /* fft.h:44 */
 #endif
+/* a caller that had its own NTAPS / GAIN / NFFT before this header is accepted only if they are the reference's: rrc_fir()
+ * reads and writes memory[127] whatever the caller thinks NTAPS is, fft()/ifft() transform 512 points */
+#if NTAPS != 127 || NFFT != 512
+#error "qpsk_dropin.h: NTAPS / NFFT are defined with other values than the reference's (rrc_fir.h:13: 127, fft.h:44: 512); the library's rrc_fir() and fft() use those"
+#endif
+/* GAIN is a floating constant: the preprocessor cannot compare it and C11 has no constant expression for it; C++ checks it */
+#ifdef __cplusplus
+#define QPSK_DROPIN_CHECK_GAIN static_assert(GAIN == 1.85, "qpsk_dropin.h: GAIN is defined with another value than the reference's (rrc_fir.h:14)")
+QPSK_DROPIN_CHECK_GAIN;
+#undef QPSK_DROPIN_CHECK_GAIN
+#endif
 
 /* ---- configuration that the reference hard-codes ---------------------- */
 /* p->fs, rs, frame_size replace FS, RS, FRAME_SIZE (qpsk.h:16-23); center_hz replaces CENTER

@@ -102,6 +102,9 @@ void qpsk_params_default(qpsk_params *p);
 int qpsk_ctx_create(qpsk_ctx **out, int device, const qpsk_params *p, void *stream);
 void qpsk_ctx_destroy(qpsk_ctx *ctx);
 int qpsk_ctx_sync(qpsk_ctx *ctx);
+/* the kernels' status word WITHOUT a synchronisation: QPSK_OK, or what a kernel that has completed so far flagged (as qpsk_ctx_sync()
+ * would report it).  For callers that order their own streams and events against the context's (include below: MULTI does). */
+int qpsk_ctx_check(qpsk_ctx *ctx);
 int qpsk_ctx_set_stream(qpsk_ctx *ctx, void *stream);
 /* Kernel-geometry selection for tests and measurements (never needed for results: every geometry computes the same
  * bits).  Names: "QPSK_PIPE_V", "QPSK_PIPE_G", "QPSK_PIPE_NF", "QPSK_PIPE_LAYOUT_LO", "QPSK_PIPE_LAYOUT_HI", "QPSK_PIPE_DBG" (layout
@@ -231,6 +234,14 @@ int qpsk_fft_batch(qpsk_ctx *ctx, const double *d_in, double *d_out, int nbatch,
  * line, previous block's symbols, Costas phase/frequency, mixer phase.
  * Results are those of the PREVIOUS block (qpsk.c:186-197), as in the
  * reference.
+ *
+ * Error contract (all-or-poisoned).  A stream call enqueues several kernels.  If it fails between its launches (QPSK_ERR_HIP,
+ * QPSK_ERR_ALLOC), or a kernel of a stream call reports that it gave up a bounded wait (QPSK_ERR_HIP from the call that
+ * synchronises next), the carried state of ALL the context's streams is undefined: every later stream call -- the three
+ * qpsk_streams_rx_*() and qpsk_streams_set/get_loop_state() -- returns QPSK_ERR_STATE until qpsk_streams_reset() has
+ * completed successfully (a reset that itself fails leaves them refused).  Argument errors and QPSK_ERR_RANGE (a NaN / Inf
+ * sample, a loop phase beyond the bounded wrap: flagged NUMBERS, the kernels completed) do not poison, and neither does a
+ * failing batch call while no stream work is in flight.
  * ------------------------------------------------------------------------- */
 int qpsk_streams_reset(qpsk_ctx *ctx, int nstreams, double mixer_hz);
 /* the carried Costas state, h_state[nstreams][2] = (phase, freq): set_phase()/set_frequency() and
@@ -287,6 +298,58 @@ int qpsk_interleave_batch(qpsk_ctx *ctx, uint8_t *d_data, int npackets, int nbyt
 int qpsk_scramble_batch(qpsk_ctx *ctx, uint8_t *d_sym, int npackets, int nsym);
 
 /* -------------------------------------------------------------------------
+ * MULTI: a batch of independent frames sharded over the GPUs of one node
+ * (SURVEY.md 8(e)).  It stands where the reference has
+ *     while (fread(frame, ...)) rx_frame(frame);                 qpsk.c:344-354
+ * over process-global per-frame state (qpsk.c:36-53, costas_loop.c:13-23):
+ * every frame is its own modem here, shard r of N takes the contiguous
+ * frames [r F / N, (r + 1) F / N), one qpsk_ctx + one host thread + two
+ * streams per shard, NO collective and no traffic between devices.  Results
+ * (1 byte per symbol, freq and phase per frame) come back per device over
+ * PCIe into pinned memory on the shard's second stream -- while the next
+ * step's kernel runs -- and are written at the shard's place of the caller's
+ * host arrays.
+ *
+ *   devices[ndev]   HIP ordinals, one shard each; repeats are allowed (two
+ *                   shards on one GPU: a rehearsal on a one-GPU box)
+ *   qpsk_multi_load total_frames frames of frame_size complex samples;
+ *                   h_in = [total_frames][frame_size][2] float on the host
+ *                   (uploaded, shard by shard) or NULL = the shards' device
+ *                   buffers are allocated and left to the caller
+ *                   (qpsk_multi_shard returns them; or
+ *                   qpsk_multi_use_device_input lends one of the caller's)
+ *   rx_begin(slot)  every shard: qpsk_rx_batch into result slot 0 / 1, then
+ *                   its copy-back; returns once everything is ENQUEUED
+ *   rx_end(slot, h_sym [total][nsym], h_freq [total], h_phase [total])
+ *                   waits for that slot's copy-back on every device, checks
+ *                   the kernels' status, concatenates (any of the three may
+ *                   be NULL)
+ * Pipelined: begin(0); begin(1); end(0); begin(0); end(1); ... -- the
+ * copy-back of a step overlaps the kernel of the next.  A 16384-sample
+ * frame returns 2056 bytes: 16.1 MiB per 8192-frame step, ~0.3 ms over PCIe
+ * Gen5 x16 -- as long as the step's kernel; the copy-back, not the kernel,
+ * bounds a host that wants every step's symbols (examples/shard_devices.c,
+ * bench.py `gather`).
+ * ------------------------------------------------------------------------- */
+typedef struct qpsk_multi qpsk_multi;
+int qpsk_multi_create(qpsk_multi **out, const int *devices, int ndev, const qpsk_params *p);
+void qpsk_multi_destroy(qpsk_multi *mj);
+int qpsk_multi_shards(const qpsk_multi *mj);
+int qpsk_multi_load(qpsk_multi *mj, long long total_frames, const float *h_in);
+/* shard r: its device, first frame and frame count, context and device input buffer (any pointer may be NULL) */
+int qpsk_multi_shard(qpsk_multi *mj, int r, int *device, long long *first, long long *count, qpsk_ctx **ctx, float **d_in);
+int qpsk_multi_use_device_input(qpsk_multi *mj, int r, const float *d_in);
+/* Direct mode for a slot: its copy-back goes by DMA straight to the caller's arrays (each shard at its place) instead of to the library's
+ * pinned staging, and qpsk_multi_rx_end(slot, NULL, NULL, NULL) only waits -- no concatenating memcpy on the host (16 MiB per 8192-frame
+ * step: ~1.4 ms of one host core, five times the kernel).  The arrays must be page-locked (qpsk_host_alloc) and stay valid while the
+ * slot is used; all NULL = back to staging. */
+int qpsk_multi_set_direct_output(qpsk_multi *mj, int slot, uint8_t *h_sym, float *h_freq, float *h_phase);
+int qpsk_host_alloc(void **h_ptr, size_t bytes);      /* page-locked host memory, usable from every device */
+int qpsk_host_free(void *h_ptr);
+int qpsk_multi_rx_begin(qpsk_multi *mj, int slot);
+int qpsk_multi_rx_end(qpsk_multi *mj, int slot, uint8_t *h_sym, float *h_freq, float *h_phase);
+
+/* -------------------------------------------------------------------------
  * Small helpers so that a C host needs nothing but this library.
  * ------------------------------------------------------------------------- */
 int qpsk_dev_alloc(qpsk_ctx *ctx, void **d_ptr, size_t bytes);
@@ -298,6 +361,10 @@ int qpsk_dev_download(qpsk_ctx *ctx, void *h_dst, const void *d_src, size_t byte
  * Costas kernel uses) over the float bit patterns [first, first+count) in both signs; tests compare
  * it with the same hash of the CPU oracle over the same range. */
 int qpsk_selftest_sincos_hash(qpsk_ctx *ctx, uint32_t first, uint32_t count, unsigned long long *h_out);
+
+/* Test hook (the stream error paths, tests/test_gpu_parity.py): stores `code` in the context's kernel status word, as a kernel that gave
+ * up (1), left the bounded phase range (2) or ended on a non-finite loop state (3) would; the context's next synchronising call reports it. */
+int qpsk_test_inject_status(qpsk_ctx *ctx, int code);
 
 #ifdef __cplusplus
 }

@@ -7,5 +7,5 @@ device pointers of torch tensors (PyTorch is used for device memory and streams,
 
 There is no CPU fallback: without the built library, or without a GPU, everything raises.
 """
-from .lib import (QpskError, Modem, Params, TIMING_FIXED, TIMING_FFT, TIMING_HIST, build, lib_path, load,  # noqa: F401
+from .lib import (QpskError, Modem, MultiJob, Params, TIMING_FIXED, TIMING_FFT, TIMING_HIST, build, lib_path, load,  # noqa: F401
                   TAU, version)

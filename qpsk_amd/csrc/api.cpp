@@ -138,6 +138,7 @@ struct qpsk_ctx {
     unsigned carrier_blocks = 0;        /* blocks taken from the tables since the reset (which of the two holds the current one) */
     unsigned carrier_scans = 0;         /* stream_scan_kernel launches among them (its relay counter, kernels.h) */
     float *carrier_pending = nullptr;   /* the table stream_scan_kernel has begun: the loop kernel of the same call finishes it (carrier.h) */
+    bool stream_work_unchecked = false; /* a stream call has enqueued kernels whose status word no synchronisation has looked at yet */
     bool streams_poisoned = false;      /* a stream call failed between its launches (or a kernel gave up): carried state is undefined until the next reset */
     /* host-pointer streaming call (qpsk_streams_rx_pcm_host: what the drop-in rx_frame() uses): pinned staging on the
      * host, matching arena on the device; sized for nstreams blocks */
@@ -174,13 +175,18 @@ static int ensure(qpsk_ctx *c, DevBuf &b, size_t bytes)
 static int check_status(qpsk_ctx *c)
 {
     const int st = __atomic_exchange_n(c->h_status, 0, __ATOMIC_ACQ_REL);
+    if (st != STATUS_PIPE_TIMEOUT) c->stream_work_unchecked = false;
     if (st == STATUS_PIPE_TIMEOUT) {
-        /* a kernel gave up a bounded wait: running streams (their carried state, the shared carrier's relay counter) are undefined from here */
-        if (c->nstreams > 0) {
+        /* a kernel gave up a bounded wait.  Running streams are affected only if a STREAM call has enqueued work since the status word was
+         * last looked at (device-pointer stream calls do not synchronise: their kernels' verdict arrives here, through whichever call
+         * synchronises next); a batch call's timeout with no stream work in flight leaves the streams' carried state alone (ADVICE r5:
+         * this function used to poison them for any call) */
+        if (c->nstreams > 0 && c->stream_work_unchecked) {
             c->streams_poisoned = true;
             c->carrier_shared = false;
             c->carrier_pending = nullptr;
         }
+        c->stream_work_unchecked = false;
         return fail(QPSK_ERR_HIP, "pipeline kernel: producer/consumer wait timed out; results of the calls since the last synchronisation are invalid");
     }
     if (st == STATUS_PHASE_RANGE)
@@ -190,6 +196,15 @@ static int check_status(qpsk_ctx *c)
         return fail(QPSK_ERR_RANGE, "a Costas loop ended on a NaN / Inf state: the input held a non-finite sample (the reference hangs in phase_wrap() "
                                     "on an infinite phase, costas_loop.c:61-67); results of the calls since the last synchronisation are invalid");
     if (st != 0) return fail(QPSK_ERR_HIP, "kernel status %d", st);
+    return QPSK_OK;
+}
+
+/* test hook (tests/test_gpu_parity.py, the stream error paths): stores a kernel status code in the context's status word as a kernel
+ * that gave up would; the next synchronising call of the context reports it */
+int qpsk_test_inject_status(qpsk_ctx *c, int code)
+{
+    if (!c || !c->h_status) return fail(QPSK_ERR_ARG, "null context");
+    __atomic_store_n(c->h_status, code, __ATOMIC_RELEASE);
     return QPSK_OK;
 }
 
@@ -370,6 +385,20 @@ int qpsk_ctx_sync(qpsk_ctx *c)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return check_status(c);
+}
+
+/* the status word WITHOUT a synchronisation: what the kernels completed so far have flagged (multi.cpp looks at it behind a result
+ * slot's copy event, while the next step may already be running on the compute stream) */
+int qpsk_ctx_check(qpsk_ctx *c)
+{
+    if (!c) return fail(QPSK_ERR_ARG, "null context");
+    return check_status(c);
+}
+
+/* multi.cpp's shard threads report through the CALLING thread's error text */
+int qpsk_set_error(int code, const char *msg)
+{
+    return fail(code, "%s", msg ? msg : "");
 }
 
 int qpsk_ctx_set_stream(qpsk_ctx *c, void *stream)
@@ -1015,12 +1044,16 @@ int qpsk_fft_batch(qpsk_ctx *c, const double *d_in, double *d_out, int nbatch, i
 
 /* --------------------------------------------------------------- streams */
 static bool stream_scan_ok(const qpsk_ctx *c, bool pcm, bool shared_carrier);
+static int streams_usable(qpsk_ctx *c, const char *who);
 static bool stream_block_ok(const qpsk_ctx *c, bool pcm = true);
 
 int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
 {
     if (!c || nstreams <= 0) return fail(QPSK_ERR_ARG, "qpsk_streams_reset: bad argument");
     if (bind(c)) return QPSK_ERR_HIP;
+    /* poisoned until this call has COMPLETED: a reset that fails half way (a launch, the last synchronisation) must not leave
+     * streams that look usable over half-initialised state */
+    c->streams_poisoned = true;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (nstreams != c->nstreams) {
         free_streams(c);
@@ -1053,12 +1086,16 @@ int qpsk_streams_reset(qpsk_ctx *c, int nstreams, double mixer_hz)
     c->carrier_blocks = 0;
     c->carrier_scans = 0;
     c->carrier_pending = nullptr;
-    c->streams_poisoned = false;
     if (c->prm.frame_size % 2 == 0 && (stream_scan_ok(c, true, true) || stream_block_ok(c))) {      /* (a kernel that uses it would take these streams) */
         KERNEL_TRY(launch_carrier_table(c->s_cstate, c->s_ctab, c->prm.frame_size, false, c->stream));
         c->carrier_shared = true;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    /* the one-launch kernel's wave counter: whatever an earlier, failed call left between the host's expectation and the device's count
+     * (a polled call whose synchronisation failed had already advanced done_expect), the stream is idle now: back in step */
+    if (c->h_done) c->done_expect = *(volatile unsigned *)c->h_done;
+    (void)__atomic_exchange_n(c->h_status, 0, __ATOMIC_ACQ_REL);      /* a status word left by the call that poisoned the streams belongs to it */
+    c->streams_poisoned = false;
     return QPSK_OK;
 }
 
@@ -1074,7 +1111,7 @@ static int carrier_to_streams(qpsk_ctx *c)
 int qpsk_streams_set_loop_state(qpsk_ctx *c, const float *h_state)
 {
     if (!c || !h_state) return fail(QPSK_ERR_ARG, "null argument");
-    if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
+    if (int ru = streams_usable(c, "qpsk_streams_set_loop_state")) return ru;
     if (bind(c)) return QPSK_ERR_HIP;
     HIP_TRY(hipMemcpyAsync(c->s_loop, h_state, sizeof(float) * 2 * (size_t)c->nstreams, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1084,7 +1121,7 @@ int qpsk_streams_set_loop_state(qpsk_ctx *c, const float *h_state)
 int qpsk_streams_get_loop_state(qpsk_ctx *c, float *h_state)
 {
     if (!c || !h_state) return fail(QPSK_ERR_ARG, "null argument");
-    if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
+    if (int ru = streams_usable(c, "qpsk_streams_get_loop_state")) return ru;
     if (bind(c)) return QPSK_ERR_HIP;
     HIP_TRY(hipMemcpyAsync(h_state, c->s_loop, sizeof(float) * 2 * (size_t)c->nstreams, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1287,6 +1324,7 @@ static int streams_usable(qpsk_ctx *c, const char *who)
     if (c->nstreams <= 0) return fail(QPSK_ERR_STATE, "call qpsk_streams_reset() first");
     if (c->streams_poisoned)
         return fail(QPSK_ERR_STATE, "%s: an earlier stream call failed between its launches; the streams' carried state is undefined until qpsk_streams_reset()", who);
+    c->stream_work_unchecked = true;      /* every caller goes on to enqueue stream work (or to read what such work left) */
     return QPSK_OK;
 }
 

@@ -51,7 +51,9 @@ API_SYMBOLS = [
     "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
     "qpsk_streams_rx_pcm", "qpsk_streams_rx_pcm_host", "qpsk_dev_alloc", "qpsk_dev_free", "qpsk_dev_upload", "qpsk_dev_download",
     "qpsk_selftest_sincos_hash", "qpsk_crc16_batch", "qpsk_interleave_batch", "qpsk_scramble_batch",
-    "qpsk_tx_reset", "qpsk_tx_symbols",
+    "qpsk_tx_reset", "qpsk_tx_symbols", "qpsk_test_inject_status", "qpsk_ctx_check",
+    "qpsk_multi_create", "qpsk_multi_destroy", "qpsk_multi_shards", "qpsk_multi_load", "qpsk_multi_shard", "qpsk_multi_use_device_input",
+    "qpsk_multi_rx_begin", "qpsk_multi_rx_end", "qpsk_multi_set_direct_output", "qpsk_host_alloc", "qpsk_host_free",
 ]
 # every symbol include/qpsk_dropin.h declares
 DROPIN_SYMBOLS = [
@@ -118,6 +120,20 @@ def load():
     L.qpsk_streams_rx_pcm.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.qpsk_streams_rx_pcm_host.argtypes = [vp, vp, vp, vp, vp, vp]
     L.qpsk_selftest_sincos_hash.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong)]
+    L.qpsk_test_inject_status.argtypes = [vp, i32]
+    L.qpsk_ctx_check.argtypes = [vp]
+    L.qpsk_multi_create.argtypes = [C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(Params)]
+    L.qpsk_multi_destroy.argtypes = [vp]
+    L.qpsk_multi_destroy.restype = None
+    L.qpsk_multi_shards.argtypes = [vp]
+    L.qpsk_multi_load.argtypes = [vp, C.c_longlong, vp]
+    L.qpsk_multi_shard.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(vp), C.POINTER(vp)]
+    L.qpsk_multi_use_device_input.argtypes = [vp, i32, vp]
+    L.qpsk_multi_set_direct_output.argtypes = [vp, i32, vp, vp, vp]
+    L.qpsk_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.qpsk_host_free.argtypes = [vp]
+    L.qpsk_multi_rx_begin.argtypes = [vp, i32]
+    L.qpsk_multi_rx_end.argtypes = [vp, i32, vp, vp, vp]
     L.qpsk_crc16_batch.argtypes = [vp, vp, i32, i32, vp]
     L.qpsk_interleave_batch.argtypes = [vp, vp, i32, i32, i32]
     L.qpsk_scramble_batch.argtypes = [vp, vp, i32, i32]
@@ -403,3 +419,89 @@ class Modem:
         h = C.c_ulonglong()
         self._check(self.L.qpsk_selftest_sincos_hash(self.h, first, count, C.byref(h)))
         return h.value
+
+
+class MultiJob:
+    """qpsk_multi of include/qpsk_hip.h: a batch sharded over several devices (repeats allowed), one context + one host thread + two
+    streams per shard, results gathered into host arrays.  Plumbing for the tests and bench.py's `gather` key."""
+
+    def __init__(self, devices, **params):
+        kw = dict(fs=9600.0, rs=2400.0, frame_size=512, rrc_alpha=0.35, loop_bw=np.float32(TAU / 100.0), min_freq=-1.0, max_freq=1.0,
+                  timing_mode=TIMING_HIST, fixed_index=0)
+        kw.update(params)
+        self.L = load()
+        self.params = Params(kw["fs"], kw["rs"], kw["frame_size"], kw["rrc_alpha"], kw["loop_bw"], kw["min_freq"], kw["max_freq"],
+                             kw["timing_mode"], kw["fixed_index"])
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        self._check(self.L.qpsk_multi_create(C.byref(h), devs, len(devices), C.byref(self.params)))
+        self.h = h
+        self.frame_size = kw["frame_size"]
+        self.total = 0
+        self.nsym = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise QpskError("libqpsk_hip error %d: %s" % (rc, self.L.qpsk_last_error().decode()))
+
+    def load(self, frames_host=None, total=None):
+        """frames_host: (F, frame_size, 2) float32 numpy array uploaded shard by shard, or None with `total` (device buffers left empty)"""
+        if frames_host is not None:
+            x = np.ascontiguousarray(frames_host, np.float32)
+            total = x.shape[0]
+            self._check(self.L.qpsk_multi_load(self.h, total, x.ctypes.data_as(C.c_void_p)))
+        else:
+            self._check(self.L.qpsk_multi_load(self.h, int(total), None))
+        self.total = int(total)
+        ctx = C.c_void_p()
+        self._check(self.L.qpsk_multi_shard(self.h, 0, None, None, None, C.byref(ctx), None))
+        self.nsym = self.L.qpsk_ctx_nsym(ctx)
+
+    def shard(self, r):
+        dev, first, count, ctx, d_in = C.c_int32(), C.c_longlong(), C.c_longlong(), C.c_void_p(), C.c_void_p()
+        self._check(self.L.qpsk_multi_shard(self.h, r, C.byref(dev), C.byref(first), C.byref(count), C.byref(ctx), C.byref(d_in)))
+        return dict(device=dev.value, first=first.value, count=count.value, ctx=ctx, d_in=d_in.value)
+
+    def use_device_input(self, r, tensor):
+        self._check(self.L.qpsk_multi_use_device_input(self.h, r, C.c_void_p(tensor.data_ptr())))
+
+    def begin(self, slot):
+        self._check(self.L.qpsk_multi_rx_begin(self.h, slot))
+
+    def end(self, slot, sym=None, freq=None, phase=None):
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)      # noqa: E731
+        self._check(self.L.qpsk_multi_rx_end(self.h, slot, p(sym), p(freq), p(phase)))
+
+    def pinned_outputs(self):
+        """(sym, freq, phase) numpy views of page-locked memory (qpsk_host_alloc) for direct mode; kept alive by this object"""
+        out = []
+        for shape, dt in (((self.total, self.nsym), np.uint8), ((self.total,), np.float32), ((self.total,), np.float32)):
+            nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
+            p = C.c_void_p()
+            self._check(self.L.qpsk_host_alloc(C.byref(p), nbytes))
+            self._pinned = getattr(self, "_pinned", []) + [p]
+            buf = (C.c_uint8 * nbytes).from_address(p.value)
+            out.append(np.frombuffer(buf, dtype=dt).reshape(shape))
+        return tuple(out)
+
+    def set_direct(self, slot, sym=None, freq=None, phase=None):
+        p = lambda a: None if a is None else C.c_void_p(a.ctypes.data)      # noqa: E731
+        self._check(self.L.qpsk_multi_set_direct_output(self.h, slot, p(sym), p(freq), p(phase)))
+
+    def outputs(self):
+        return (np.empty((self.total, self.nsym), np.uint8), np.empty(self.total, np.float32), np.empty(self.total, np.float32))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.qpsk_multi_destroy(self.h)
+            self.h = None
+            for p in getattr(self, "_pinned", []):
+                self.L.qpsk_host_free(p)
+            self._pinned = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass
+

@@ -48,7 +48,7 @@ def build_c_example(out_dir, name="loopback"):
     return exe
 
 
-@pytest.mark.parametrize("name", ["loopback", "dropin_main"])
+@pytest.mark.parametrize("name", ["loopback", "dropin_main", "shard_devices"])
 def test_c_host_example_builds_and_links(qpsk_lib, tmp_path, name):
     assert os.path.exists(build_c_example(tmp_path, name))
 
@@ -74,6 +74,54 @@ def test_c_host_loopback_runs_on_every_gpu(qpsk_lib, tmp_path):
     r = subprocess.run([exe, "96", "1024"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "errors 0" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_host_shards_a_batch_over_devices_and_gathers(qpsk_lib, tmp_path):
+    """examples/shard_devices.c: a C host, one batch split into contiguous shards -- THREE shards on the devices of this box
+    (round robin: on the one-GPU box three contexts share the GPU), an odd frame count so that the shards differ in size -- every step's
+    symbols / freq / phase gathered into one host array per output, serially and with the copy-back overlapped with the next step's
+    kernel: all frames locked, the gathered arrays identical across steps and schedules"""
+    import subprocess
+    exe = build_c_example(tmp_path, "shard_devices")
+    r = subprocess.run([exe, "301", "256", "6", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "not locked (|offset estimate| >= 2 Hz): 0" in r.stdout and "identical across steps and schedules" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_multi_job_against_the_oracle(qpsk_lib, oracle):
+    """qpsk_multi_*() (include/qpsk_hip.h, MULTI) through ctypes: host frames uploaded shard by shard (two shards on device 0, 3 : 2
+    frames... an odd total), two pipelined steps into both result slots, the gathered symbols / freq / phase of EVERY frame against the
+    oracle bit for bit; then the error paths of the slot protocol"""
+    import numpy as np
+    import qpsk_amd
+    from oracle.pyoracle import TIMING_FIXED
+    from sigutil import bits_equal, make_frames
+    fs, rs, L, F = 19200.0, 2400.0, 1024, 77
+    mj = qpsk_amd.MultiJob([0, 0], fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    m = qpsk_amd.Modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=45.0, base_seed=5, noise=0.03)
+    want = oracle.rx_batch(x, fs, rs, timing_mode=TIMING_FIXED, fixed_index=6)
+    mj.load(x)
+    a, b = mj.shard(0), mj.shard(1)
+    assert (a["first"], a["count"], b["first"], b["count"]) == (0, 38, 38, 39)      # [r F / N, (r + 1) F / N): qpsk_amd/shard.py's rule
+    out0, out1 = mj.outputs(), mj.outputs()
+    mj.begin(0)
+    mj.begin(1)
+    mj.end(0, *out0)
+    mj.end(1, *out1)
+    for sym, freq, phase in (out0, out1):
+        assert np.array_equal(sym, want["sym"]) and bits_equal(freq, want["freq"]) and bits_equal(phase, want["phase"])
+    with pytest.raises(qpsk_amd.QpskError, match="nothing in flight"):
+        mj.end(0)
+    mj.begin(0)
+    with pytest.raises(qpsk_amd.QpskError, match="still in flight"):
+        mj.begin(0)
+    mj.end(0, *out0)
+    assert np.array_equal(out0[0], want["sym"])
+    mj.close()
+    m.close()
 
 
 def test_defaults_are_the_reference_literals(qpsk_lib):

@@ -466,6 +466,73 @@ def test_ragged_batches_ride_in_one_launch(oracle, F, mode):
     assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz"))
 
 
+def test_stream_calls_are_all_or_poisoned(oracle):
+    """include/qpsk_hip.h, STREAMS, error contract (no test reached these paths): a kernel of a stream call reports that it
+    gave up a bounded wait (injected through qpsk_test_inject_status: the status word a kernel would have written) -> the call that
+    synchronises next fails with QPSK_ERR_HIP, every stream call after it -- the loop-state accessors included -- is refused with
+    QPSK_ERR_STATE, qpsk_streams_reset() makes the streams usable again and what they then compute is the oracle's.  A flagged NUMBER
+    (QPSK_ERR_RANGE) does not poison, and neither does a failing BATCH call while no stream work is in flight."""
+    import qpsk_amd
+    fs, rs, L, n = 19200.0, 2400.0, 1024, 6
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    x, _ = make_frames(3 * n, L, 8, m.taps, fs, offset_hz=35.0, base_seed=91, noise=0.03)
+    blocks = x.reshape(3, n, L, 2)
+
+    def run_blocks():
+        m.streams_reset(n)
+        out = [m.streams_rx_cplx(blocks[b], want_costas=False) for b in range(3)]
+        m.sync()
+        return out
+
+    def rc_of(fn):
+        try:
+            fn()
+            return 0
+        except qpsk_amd.QpskError as e:
+            return e.args[0] if e.args and isinstance(e.args[0], int) else str(e)
+
+    ref = run_blocks()
+    want_state = m.streams_loop_state()
+    # 1. a stream kernel "gave up": the next synchronisation reports it, then everything is refused until the reset
+    m.streams_reset(n)
+    m.streams_rx_cplx(blocks[0], want_costas=False)
+    m._check(m.L.qpsk_test_inject_status(m.h, 1))
+    assert "timed out" in str(rc_of(m.sync)), "the injected pipeline time-out was not reported"
+    for call in (lambda: m.streams_rx_cplx(blocks[1], want_costas=False), m.streams_loop_state,
+                 lambda: m._check(m.L.qpsk_streams_set_loop_state(m.h, (C.c_float * (2 * n))()))):
+        msg = str(rc_of(call))
+        assert "qpsk_streams_reset" in msg, msg
+    # 2. the reset clears it, and the streams compute the oracle's bits again, block after block
+    m.streams_reset(n)
+    om = [oracle.modem(fs, rs, L, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=6) for _ in range(n)]
+    for b in range(3):
+        o = m.streams_rx_cplx(blocks[b], want_costas=False)
+        m.sync()
+        for s_ in range(n):
+            om[s_].rx_cplx(blocks[b][s_])
+            assert bits_equal(cpu(o["sym"][s_]), om[s_].symbols), (b, s_)
+            assert cpu(o["phase"])[s_] == om[s_].phase and cpu(o["freq"])[s_] == om[s_].freq, (b, s_)
+            assert bits_equal(cpu(o["sym"][s_]), cpu(ref[b]["sym"][s_]))
+    assert bits_equal(m.streams_loop_state(), want_state)
+    # 3. a flagged number does not poison
+    m.streams_reset(n)
+    m.streams_rx_cplx(blocks[0], want_costas=False)
+    m._check(m.L.qpsk_test_inject_status(m.h, 3))
+    assert "NaN" in str(rc_of(m.sync))
+    m.streams_rx_cplx(blocks[1], want_costas=False)          # not refused
+    m.sync()
+    # 4. a batch call's time-out with no stream work in flight leaves the streams alone
+    m.streams_reset(n)
+    m.rx_batch(blocks[0])
+    m._check(m.L.qpsk_test_inject_status(m.h, 1))
+    assert "timed out" in str(rc_of(m.sync))
+    out = [m.streams_rx_cplx(blocks[b], want_costas=False) for b in range(3)]
+    m.sync()
+    for a, b in zip(out, ref):
+        for k in ("sym", "freq", "phase"):
+            assert bits_equal(cpu(a[k]), cpu(b[k])), k
+
+
 def test_full_size_config2_bench_stimulus_every_frame(oracle):
     """the batch bench.py TIMES: config 2 at full size built by the library's own transmit chain (bench.tx_frames_gpu, the default
     --stimulus tx, rank 0's seed) -- EVERY one of the 4096 frames against the oracle, bit for bit (the oracle's fixed-offset path runs

@@ -23,12 +23,15 @@ for L, F, ix in ((1024, 8192, 6), (2048, 4608, 0), (1536, 8192, 2), (1024, 5120,
     x, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=35.0, base_seed=L + ix, noise=0.04)
     want = orc.rx_batch(x, fs, rs, timing_mode=TIMING_FIXED, fixed_index=ix, threads=16)
     xd = torch.from_numpy(x).cuda()
-    for dbg in (0, 131072, 1048576):
-        m.tune(pipe_dbg=dbg if dbg else None)
+    # (round 5's first build selected LDS-DMA staging with QPSK_PIPE_DBG bit 131072; it is the product default behind QPSK_LEAN_DMA since
+    # -- 0: through registers, 1: DMA with a window per unit where the LDS allows, 2: DMA with one window per FIR wave -- and the bit is gone:
+    # ADVICE r5.  Round 6 adds the serial wave's lane pairing, QPSK_LEAN_PAIR 0 / 2.  dbg 1048576 = frame-alternating loads, measurement build only.)
+    for dbg, dma, pair in ((0, 1, 0), (0, 0, 0), (0, 2, 0), (0, 1, 2), (0, 0, 2), (1048576, 1, 0)):
+        m.tune(pipe_dbg=dbg if dbg else None, lean_dma=dma, lean_pair=pair)
         got = m.rx_batch(xd)
         m.sync()
         ok = all(np.array_equal(got[k].cpu().numpy().view(np.uint8), want[k].view(np.uint8)) for k in ("sym", "freq", "phase"))
-        print("L %5d F %5d index %d dbg %8d %-16s %s" % (L, F, ix, dbg, m.last_kernel(), "bit-exact" if ok else "DIFFERS"), flush=True)
+        print("L %5d F %5d index %d dbg %8d lean_dma %d lean_pair %d %-16s %s" % (L, F, ix, dbg, dma, pair, m.last_kernel(), "bit-exact" if ok else "DIFFERS"), flush=True)
         bad += not ok
         if not ok:
             sys.exit(1)         # one wrong variant: stop, nothing further touches the GPU

@@ -13,9 +13,11 @@ if [ ${PIPESTATUS[0]} -ne 0 ] || grep -q "Memory access fault\|DIFFERS" $O; then
     exit 1
 fi
 {
-echo "== measurement build.  QPSK_PIPE_DBG: 0 the kernel; 131072 LDS-DMA window staging; 65536 no staging writes; 262144 no symbol stores; 524288 no hand-over"
+# NOTE (round 6): bit 131072 selected LDS-DMA staging only in round 5's FIRST build (the one profiles/r05_energy_ledger.txt session 1-2 were taken on);
+# DMA has been the product default behind QPSK_LEAN_DMA since, the bit no longer exists, and "8192" vs "8192:0:lean_dma=0" is the pair to run today.
+echo "== measurement build.  QPSK_PIPE_DBG: 0 the kernel; 131072 LDS-DMA window staging (first round-5 build only, see the note above); 65536 no staging writes; 262144 no symbol stores; 524288 no hand-over"
 echo "   write of the symbols; 1048576 loads frame-alternating (1 KB visits); 2097152 a workgroup's frames a grid apart; 3 floor (no filter arithmetic, no recurrence);"
 echo "   pitch=16448: frames 16384 + 64 samples apart"
-QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so timeout -k 10 900 python3 tools/power_probe.py 8192 8192:131072 8192:65536 8192 8192:131072 2>&1 | grep -v amdgpu.ids
+QPSK_HIP_LIB=qpsk_amd/libqpsk_hip_prof.so timeout -k 10 900 python3 tools/power_probe.py 8192 8192:0:lean_dma=0 8192:65536 8192 8192:0:lean_dma=0 2>&1 | grep -v amdgpu.ids
 } >> $O 2>&1
 tail -5 $O
