@@ -73,6 +73,7 @@ struct Tuning {
     int stream_block = -1;                            /* streams: 0 = never the one-launch-per-block kernel (streamblock.hip), 1 = whenever the shape allows, unset: by samples per block of all streams (stream_block_ok: 3.5 M for PCM, 0.4 M for complex input at CYCLES 8) */
     int stream_carrier = -1;                          /* stream_scan_kernel on PCM: 0 = every stream runs its own carrier (mixer wave) even while all streams share one */
     int lean_dma = -1;                                /* rx_lean_kernel: 0 = window staging through registers even where LDS-DMA applies (even decimation offsets), 2 = LDS-DMA with one window per FIR wave */
+    int est_waves = -1;                               /* rx_lean_kernel, in-launch FFT estimate: hardware waves launched for it */
     int lean_pair = -1;                               /* rx_lean_kernel: 0 = one lane per loop in the serial wave, 1 = two lanes per loop up to 16 frames per workgroup, 2 = up to 32; unset: up to 24, where it pays in steady state (profiles/r06_step_cost.txt) */
     int fft_fused = -1;                               /* FFT timing estimate: 0 = always a launch of its own (1 / unset: inside rx_fused_pipe_kernel's launch for full workgroups) */
 };
@@ -87,6 +88,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
     {"QPSK_STREAM_BLOCK", &Tuning::stream_block}, {"QPSK_STREAM_POLL", &Tuning::stream_poll},
     {"QPSK_STREAM_SCAN", &Tuning::stream_scan}, {"QPSK_STREAM_CARRIER", &Tuning::stream_carrier},
     {"QPSK_LEAN_DMA", &Tuning::lean_dma},     {"QPSK_LEAN_PAIR", &Tuning::lean_pair},
+    {"QPSK_EST_WAVES", &Tuning::est_waves},
 };
 
 /* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
@@ -615,6 +617,7 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
     a.dbg = tuned(c->tune.pipe_variant, 0) & PIPE_VARIANT_MASK;
     a.lean_dma = tuned(c->tune.lean_dma, 1) != 0;
     a.lean_twowin = tuned(c->tune.lean_dma, 1) != 2 ? 1 : 0;      /* QPSK_LEAN_DMA = 2: LDS-DMA, but one window per FIR wave whatever the LDS allows */
+    a.est_waves = tuned(c->tune.est_waves, 0);
     a.lean_pair = tuned(c->tune.lean_pair, 3);      /* 3: the library's own rule (launch_rx_lean) */
     a.taps = c->d_taps;
     a.gains = c->d_gains;

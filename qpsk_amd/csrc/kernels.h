@@ -38,6 +38,7 @@ struct FusedArgs {
                                a window of its own, so a two-unit FIR wave's DMAs run a whole unit ahead (fir_lean_loop2_dma2w) */
     int lean_dma;           /* rx_lean_kernel: 1 = FIR waves whose frames all have an even decimation offset stage their windows by LDS-DMA
                                (fir_lean_asm.h, the _dma loops); 0 = always through registers.  Same bits either way ("QPSK_LEAN_DMA") */
+    int est_waves;          /* rx_lean_kernel with the FFT timing estimate inside the launch: hardware waves launched for it (0 = the library's 12, the most the register budget allows) ("QPSK_EST_WAVES") */
     int lean_pair;          /* rx_lean_kernel: the serial wave runs every loop in TWO lanes that share the step's sin/cos polynomial chains
                                (costas_asm.h, QPSK_BODY_P): 1 = in workgroups of up to 16 frames, 2 = up to 32, 3 = up to 24 (the library's rule), 0 = never; launch_rx_lean turns the wish into 0 / 1.  Same bits ("QPSK_LEAN_PAIR") */
     int dbg;                /* layout variants of the pipeline kernel, all bit-exact (qpsk_ctx_set_tuning "QPSK_PIPE_DBG"):

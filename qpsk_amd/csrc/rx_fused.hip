@@ -1842,7 +1842,13 @@ static LeanGeometry lean_geometry(const FusedArgs &a, int G, unsigned long long 
     g.lds = lean_lds_bytes(G, g.nwin);
     /* the FFT timing estimate inside the launch: at least eight hardware waves share the workgroup's frames (waves without a unit retire
      * after it), at most MAX_FPW frames per wave, estimator windows in the frame windows, taps + indices behind the rows */
-    g.hw_est = g.hw < 8 ? 8 : g.hw;
+    {
+        /* twelve hardware waves (three per SIMD: the kernel's register budget) share the workgroup's frames: 0.1654 ms against 0.1692 with
+         * eight at config 3, launches interleaved in one process (profiles/r06_config3.txt) */
+        const int want = a.est_waves > 0 ? a.est_waves : 12;
+        g.hw_est = g.hw < want ? want : g.hw;
+        if (g.hw_est > MAX_THREADS / 64) g.hw_est = MAX_THREADS / 64;
+    }
     const int room = (int)((size_t)g.nwin * UF * lean::WS / tfft::WSLOTS);
     g.nwe = g.hw_est < room ? g.hw_est : room;
     g.lds_est = g.lds + LEAN_EST_LDS_BYTES;
