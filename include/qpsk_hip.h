@@ -116,7 +116,11 @@ int qpsk_ctx_set_stream(qpsk_ctx *ctx, void *stream);
  * timing: 1 = mixer + filter + scan as one kernel whatever the stream count, 0 = never), "QPSK_STREAM_CARRIER" (0: that kernel runs every
  * stream's carrier recurrence although all streams share one), "QPSK_LEAN_DMA" (0: rx_lean_kernel stages its filter windows through
  * registers even where it would use LDS-DMA: frames with an even timing offset; 2: LDS-DMA, but one window per FIR wave even where the LDS
- * has room for one per two-frame unit), "QPSK_LEAN_PAIR" (rx_lean_kernel's serial wave: 0 = one lane per Costas loop, 1 = two lanes per
+ * has room for one per two-frame unit), "QPSK_HIST_ONEPASS" (histogram timing: 0 = always the two-launch route -- timing scan, then the receive kernel -- 1 = the one-pass
+ * route, rx_hist_kernel on the previous batch's majority index plus a fall-back pass over the frames it missed, whenever a guess exists;
+ * unset: that route only while every frame of the context's last histogram-mode batch sat on that batch's majority index -- a missed
+ * frame costs more than the route saves), "QPSK_EST_WAVES" (hardware waves that share the
+ * in-launch FFT timing estimate), "QPSK_LEAN_PAIR" (rx_lean_kernel's serial wave: 0 = one lane per Costas loop, 1 = two lanes per
  * loop -- they share the step's sine / cosine polynomial chains -- in workgroups of up to 16 frames, 2 = up to 32; the library's own choice is up to 24); value < 0 = back to
  * the library's own choice.
  * Environment variables of the same names are read once, by qpsk_ctx_create(), as the context's initial values;
@@ -365,6 +369,9 @@ int qpsk_selftest_sincos_hash(qpsk_ctx *ctx, uint32_t first, uint32_t count, uns
 /* Test hook (the stream error paths, tests/test_gpu_parity.py): stores `code` in the context's kernel status word, as a kernel that gave
  * up (1), left the bounded phase range (2) or ended on a non-finite loop state (3) would; the context's next synchronising call reports it. */
 int qpsk_test_inject_status(qpsk_ctx *ctx, int code);
+/* Test hook (the one-pass histogram route): synchronises, then out[5] = {the guess the next histogram-mode call will take (-1: none), frames
+ * the last one-pass call's guess missed, and the statistics the host steers by: majority index, frames, frames off the majority or missed by the guess} */
+int qpsk_test_hist_state(qpsk_ctx *ctx, int32_t *out);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,7 @@ struct Tuning {
     int stream_block = -1;                            /* streams: 0 = never the one-launch-per-block kernel (streamblock.hip), 1 = whenever the shape allows, unset: by samples per block of all streams (stream_block_ok: 3.5 M for PCM, 0.4 M for complex input at CYCLES 8) */
     int stream_carrier = -1;                          /* stream_scan_kernel on PCM: 0 = every stream runs its own carrier (mixer wave) even while all streams share one */
     int lean_dma = -1;                                /* rx_lean_kernel: 0 = window staging through registers even where LDS-DMA applies (even decimation offsets), 2 = LDS-DMA with one window per FIR wave */
+    int hist_onepass = -1;                            /* histogram timing: 0 = never the one-pass route (rx_hist_kernel on the previous batch's majority index + a fall-back pass), 1 = whenever the shape allows and a guess exists (unset: only while every frame of the last batch sat on its majority index) */
     int est_waves = -1;                               /* rx_lean_kernel, in-launch FFT estimate: hardware waves launched for it */
     int lean_pair = -1;                               /* rx_lean_kernel: 0 = one lane per loop in the serial wave, 1 = two lanes per loop up to 16 frames per workgroup, 2 = up to 32; unset: up to 24, where it pays in steady state (profiles/r06_step_cost.txt) */
     int fft_fused = -1;                               /* FFT timing estimate: 0 = always a launch of its own (1 / unset: inside rx_fused_pipe_kernel's launch for full workgroups) */
@@ -88,7 +89,7 @@ static const struct { const char *name; int Tuning::*field; } TUNING_KEYS[] = {
     {"QPSK_STREAM_BLOCK", &Tuning::stream_block}, {"QPSK_STREAM_POLL", &Tuning::stream_poll},
     {"QPSK_STREAM_SCAN", &Tuning::stream_scan}, {"QPSK_STREAM_CARRIER", &Tuning::stream_carrier},
     {"QPSK_LEAN_DMA", &Tuning::lean_dma},     {"QPSK_LEAN_PAIR", &Tuning::lean_pair},
-    {"QPSK_EST_WAVES", &Tuning::est_waves},
+    {"QPSK_EST_WAVES", &Tuning::est_waves},   {"QPSK_HIST_ONEPASS", &Tuning::hist_onepass},
 };
 
 /* layout bits a product build honours: 4 no spare waves, 8 C++ Costas step, 64/128 lane-mapping variants.  The
@@ -123,7 +124,14 @@ struct qpsk_ctx {
     int *h_status = nullptr;     /* host view */
     int *d_status = nullptr;     /* device view of the same word */
     std::vector<float> h_gains;
-    DevBuf index, filtered, mixed, keystream, sympad;
+    DevBuf index, filtered, mixed, keystream, sympad, mislist;
+    /* the one-pass histogram route (rx_hist_kernel): d_hint[0] = the guessed decimation offset = the majority index of the context's last
+     * histogram-mode batch (left there by index_majority_kernel, in stream order: no synchronisation), d_hint[1] = the frames the guess
+     * missed in the running call; h_hist_stats (pinned, written by that kernel) = {majority, frames, missed} of the last batch whose
+     * kernels have completed: the host reads it to stay away from the route while the guess misses many frames */
+    int32_t *d_hint = nullptr;
+    int32_t *h_hist_stats = nullptr, *d_hist_stats = nullptr;
+    bool hint_valid = false;
     int keystream_len = 0;
     std::map<int, double *> twiddles;
     float *d_fast = nullptr;      /* qpsk_rrc_fir_batch_fast: H[512][2] then tw[512][2]; rebuilt when the taps change */
@@ -207,6 +215,23 @@ int qpsk_test_inject_status(qpsk_ctx *c, int code)
 {
     if (!c || !c->h_status) return fail(QPSK_ERR_ARG, "null context");
     __atomic_store_n(c->h_status, code, __ATOMIC_RELEASE);
+    return QPSK_OK;
+}
+
+/* test hook: the one-pass histogram route's books after a synchronisation -- out[0] = the guess the next call will take (-1: none), out[1] = frames
+ * the last one-pass call's guess missed, out[2..4] = the statistics the host reads (majority, frames, missed) */
+int qpsk_test_hist_state(qpsk_ctx *c, int32_t *out)
+{
+    if (!c || !out) return fail(QPSK_ERR_ARG, "null argument");
+    out[0] = out[1] = out[2] = out[3] = out[4] = -1;
+    if (!c->d_hint) return QPSK_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int32_t h[2];
+    HIP_TRY(hipMemcpy(h, c->d_hint, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = c->hint_valid ? h[0] : -1;
+    out[1] = h[1];
+    out[2] = c->h_hist_stats[0]; out[3] = c->h_hist_stats[1]; out[4] = c->h_hist_stats[2];
     return QPSK_OK;
 }
 
@@ -374,6 +399,9 @@ void qpsk_ctx_destroy(qpsk_ctx *c)
     hipFree(c->mixed.p);
     hipFree(c->keystream.p);
     hipFree(c->sympad.p);
+    hipFree(c->mislist.p);
+    if (c->d_hint) hipFree(c->d_hint);
+    if (c->h_hist_stats) hipHostFree(c->h_hist_stats);
     for (auto &kv : c->twiddles) hipFree(kv.second);
     hipFree(c->d_fast);
     free_streams(c);
@@ -747,6 +775,52 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
         if (rp) return rp;
     }
 
+    /* ---- histogram timing in ONE pass (round 6; rx_fused.hip, rx_hist_kernel): where the context has a guess -- the majority index of
+     * its previous histogram-mode batch -- the scan kernel's workgroup runs the receive path on that guess while it scans, the frames
+     * whose true index differs are redone by a fall-back pass over their list (usually empty), and the batch's own majority becomes
+     * the next guess.  No guess yet, a shape the kernel does not serve, or a last batch that missed more than an eighth of its frames
+     * (a batch of mixed indices: the fall-back pass would carry it): the two-launch route below. */
+    const bool hist_mode = c->prm.timing_mode == QPSK_TIMING_HIST;
+    if (hist_mode && pipe_ok && c->taps_symmetric && scan_fused_ok(c, d_in) && c->tune.pipe_v < 0) {      /* (QPSK_PIPE_V asks for one of the receive kernels by name) */
+        if (!c->d_hint) {
+            HIP_TRY(hipMalloc((void **)&c->d_hint, 2 * sizeof(int32_t)));
+            HIP_TRY(hipMemset(c->d_hint, 0, 2 * sizeof(int32_t)));
+            HIP_TRY(hipHostMalloc((void **)&c->h_hist_stats, 4 * sizeof(int32_t), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void **)&c->d_hist_stats, c->h_hist_stats, 0));
+            c->h_hist_stats[0] = c->h_hist_stats[1] = c->h_hist_stats[2] = -1;
+            c->hint_valid = false;
+        }
+        FusedArgs ah = a;
+        const int op = tuned(c->tune.hist_onepass, -1);
+        /* the route pays only while the guess holds for EVERY frame: a frame it misses goes through the fall-back pass, whose one
+         * workgroup takes 0.4 ms whatever the count (a serial chain again) against the 0.07 ms the route saves.  Every histogram-mode call
+         * leaves behind how many frames of its batch were off the batch's majority index (or missed by its guess): zero = try the route */
+        const int seen = __atomic_load_n(&c->h_hist_stats[1], __ATOMIC_ACQUIRE), off_majority = __atomic_load_n(&c->h_hist_stats[2], __ATOMIC_ACQUIRE);
+        const bool guess_is_good = seen > 0 && off_majority == 0;
+        if (op != 0 && c->hint_valid && (op == 1 || guess_is_good) && rx_hist_shape_ok(ah)) {
+            int r1 = ensure(c, c->index, sizeof(int32_t) * (size_t)nframes);
+            if (r1) return r1;
+            r1 = ensure(c, c->mislist, sizeof(int32_t) * (size_t)nframes);
+            if (r1) return r1;
+            int32_t *mis_count = c->d_hint + 1;      /* zero: allocation, then every index_majority_kernel */
+            KERNEL_TRY(launch_rx_hist(ah, (int32_t *)c->index.p, c->d_hint, (int32_t *)c->mislist.p, mis_count, c->d_status, c->stream));
+            /* the fall-back pass: the generic chunked kernel over the listed frames with their true indices (its grid is sized for the
+             * whole batch: the list's length is known on the device only; workgroups beyond it retire at once) */
+            FusedArgs af = a;
+            af.index = (const int32_t *)c->index.p;
+            af.frame_list = (const int32_t *)c->mislist.p;
+            af.frame_list_count = mis_count;
+            af.G = 4;
+            af.S = 64;
+            KERNEL_TRY(launch_rx_fused(af, c->stream));
+            KERNEL_TRY(launch_index_majority((const int32_t *)c->index.p, nframes, c->d_hint, mis_count, c->d_hist_stats, c->stream));
+            c->last_kernel = "rx_hist_kernel (one pass on the guessed index) + rx_fused_kernel (fall-back list)";
+            if (d_index)
+                HIP_TRY(hipMemcpyAsync(d_index, c->index.p, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToDevice, c->stream));
+            return QPSK_OK;
+        }
+    }
+
     /* ---- the timing estimate.  BASELINE config 3's shape -- FFT estimate, ONE launch of rx_fused_pipe_kernel in full 16-frame
      * workgroups, as the plan says -- runs the estimate inside the receive launch (rx_fused.hip); every other plan gets its indices
      * from a launch in front (timing_fft_kernel / timing_scan_kernel / ...). */
@@ -815,6 +889,11 @@ static int rx_batch_common(qpsk_ctx *c, const float *d_in, long long frame_pitch
             if (rc2) return rc2;
             c->last_kernel = lk;
         }
+    }
+    if (hist_mode && c->d_hint && idx && tuned(c->tune.hist_onepass, -1) != 0) {
+        /* the batch's majority index as the next histogram-mode call's guess (one workgroup, in stream order) */
+        KERNEL_TRY(launch_index_majority(idx, nframes, c->d_hint, c->d_hint + 1, c->d_hist_stats, c->stream));
+        c->hint_valid = true;
     }
     if (main_pl.kind == K_LEAN && (nframes & 1)) {
         /* the last frame of an odd batch shares its two-frame unit with a pad frame: the unit's rows are pad rows (rx_fused.hip,

@@ -54,6 +54,10 @@ struct FusedArgs {
     const float2 *refill;
     float2 *refill_dst;     /* = dsrc, writable */
     int refill_planar;      /* refill rows are [cycles][nsym] planes (phase-major: what stream_scan_kernel leaves) instead of frame_size samples */
+    /* rx_fused_kernel as the fall-back pass of the one-pass histogram route (rx_hist_kernel, rx_fused.hip): the launch covers the frames
+     * frame_list[0 .. *frame_list_count) instead of 0 .. nframes (both in device memory: the count is known only on the device; workgroups
+     * beyond it retire at once); inputs, per-frame index and every output are addressed by the listed frame number.  NULL = off */
+    const int32_t *frame_list, *frame_list_count;
     const float *taps;      /* [127] */
     const float *gains;     /* [nbw][2] alpha, beta */
     int nbw;
@@ -101,6 +105,10 @@ unsigned long long lean_default_layout(int NU);         /* rx_lean_kernel: 1, 5,
 bool lean_shape_ok(const FusedArgs &a, int G);          /* one loop per frame, whole chunks, whole even workgroups, ... */
 int launch_rx_lean(const FusedArgs &a, int G, unsigned long long layout, int *status, hipStream_t s);
 bool lean_est_ok(const FusedArgs &a, int G, unsigned long long layout);   /* the FFT timing estimate inside rx_lean_kernel's launch fits this geometry */
+/* rx_fused.hip: the reference's histogram timing mode in ONE pass (timing scan + receive path on a guessed index, verified per frame) */
+bool rx_hist_shape_ok(const FusedArgs &a);
+int launch_rx_hist(const FusedArgs &a, int32_t *index_true, const int32_t *hint, int32_t *mis_list, int32_t *mis_count, int *status, hipStream_t s);
+int launch_index_majority(const int32_t *index, int nframes, int32_t *hint, int32_t *mis_count, int32_t *h_stats, hipStream_t s);
 int launch_rrc_fir(const float *x, const float *memory, float *y, const float *taps, int nframes, int length,
                    hipStream_t s, size_t in_pitch = 0);      /* in_pitch: samples between input frames (0 = length) */
 /* firstream.hip: the same filter as the generated stream fir_full8s_asm.h (SYMMETRIC taps only: the caller checks) */

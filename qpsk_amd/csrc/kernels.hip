@@ -52,16 +52,23 @@ rx_fused_kernel(FusedArgs a)
     float2 *ds = xs + (size_t)G * W;                                        /* [G][S] decimated symbols */
     float2 *zs = ds + (size_t)G * S;                                        /* [G*nbw][S] costas_frame staging */
     uint8_t *ss = reinterpret_cast<uint8_t *>(zs + (size_t)G * nbw * S);    /* [G*nbw][S] symbol staging */
-    int *idx = reinterpret_cast<int *>(ss + (size_t)G * nbw * S);           /* [G] */
+    int *idx = reinterpret_cast<int *>(ss + (size_t)G * nbw * S);           /* [G], then the G frame numbers */
+    int *fid = idx + G;
 
     const int tid = threadIdx.x;
     const int f0 = blockIdx.x * G;
-    const int gcount = min(G, a.nframes - f0);
+    /* the frames of this launch: 0 .. nframes, or the listed ones (the fall-back pass of rx_hist_kernel: count known on the device only) */
+    const int total = a.frame_list_count ? min(*a.frame_list_count, a.nframes) : a.nframes;
+    if (f0 >= total) return;
+    const int gcount = min(G, total - f0);
 
     if (tid < 128)
         taps[tid] = tid < NTAPS ? a.taps[tid] : 0.0f;
-    if (tid < G)
-        idx[tid] = (tid < gcount) ? (a.index ? a.index[f0 + tid] : a.fixed_index) : 0;
+    if (tid < G) {
+        const int fr = tid < gcount ? (a.frame_list ? a.frame_list[f0 + tid] : f0 + tid) : 0;
+        fid[tid] = fr;
+        idx[tid] = (tid < gcount) ? (a.index ? a.index[fr] : a.fixed_index) : 0;
+    }
 
     /* Costas lane state (wave 0 only) */
     const int lane_g = tid / nbw, lane_b = tid % nbw;
@@ -69,15 +76,15 @@ rx_fused_kernel(FusedArgs a)
     Loop st = {0.0f, 0.0f};
     bool over = false;   /* a phase beyond the bounded 2 pi wrap (qpsk_device.h) */
     LoopGains lg = {0.0f, 0.0f, a.min_freq, a.max_freq};
+    __syncthreads();
     if (costas_lane) {
         lg.alpha = a.gains[2 * lane_b];
         lg.beta = a.gains[2 * lane_b + 1];
         if (a.state_in) {
-            st.phase = a.state_in[2 * ((size_t)(f0 + lane_g) * nbw + lane_b)];
-            st.freq = a.state_in[2 * ((size_t)(f0 + lane_g) * nbw + lane_b) + 1];
+            st.phase = a.state_in[2 * ((size_t)fid[lane_g] * nbw + lane_b)];
+            st.freq = a.state_in[2 * ((size_t)fid[lane_g] * nbw + lane_b) + 1];
         }
     }
-    __syncthreads();
 
     const int nchunks = (N + S - 1) / S;
     for (int c = 0; c < nchunks; c++) {
@@ -90,7 +97,7 @@ rx_fused_kernel(FusedArgs a)
             const int n = base + w;
             float2 v = make_float2(0.0f, 0.0f);
             if (n >= 0 && n < L)
-                v = a.x[(size_t)(f0 + g) * a.frame_pitch + n];
+                v = a.x[(size_t)fid[g] * a.frame_pitch + n];
             xs[(size_t)g * W + w] = v;
         }
         __syncthreads();
@@ -131,7 +138,7 @@ rx_fused_kernel(FusedArgs a)
             const int rows = gcount * nbw;
             for (int i = tid; i < rows * cnt; i += FUSED_THREADS) {
                 const int r = i / cnt, j = i - r * cnt;
-                const size_t o = ((size_t)f0 * nbw + r) * N + sym0 + j;
+                const size_t o = ((size_t)fid[r / nbw] * nbw + r % nbw) * N + sym0 + j;
                 a.sym[o] = ss[(size_t)r * S + j];
                 if (a.costas)
                     a.costas[o] = zs[(size_t)r * S + j];
@@ -142,7 +149,7 @@ rx_fused_kernel(FusedArgs a)
     }
 
     if (costas_lane) {
-        const size_t o = (size_t)(f0 + lane_g) * nbw + lane_b;
+        const size_t o = (size_t)fid[lane_g] * nbw + lane_b;
         if (a.freq) a.freq[o] = st.freq;
         if (a.phase) a.phase[o] = st.phase;
         if (a.hz) a.hz[o] = (float)((double)st.freq * a.rs / TAU); /* qpsk.c:217 */
@@ -162,7 +169,7 @@ size_t fused_lds_bytes(int G, int S, int cycles, int nbw)
     size_t b = 512 + sizeof(float2) * ((size_t)G * W + (size_t)G * S + (size_t)G * nbw * S);
     b += (size_t)G * nbw * S;      /* ss */
     b = (b + 15) & ~(size_t)15;
-    b += sizeof(int) * (size_t)G;  /* idx */
+    b += sizeof(int) * 2 * (size_t)G;  /* idx, fid */
     return b;
 }
 

@@ -44,6 +44,8 @@
 #include <stdint.h>
 #include "qpsk_device.h"
 #include "costas_asm.h"
+#include "costas_asm_lo.h"     /* the same streams with the VGPR block at v84..v127 (rx_hist_kernel: four waves on a SIMD) */
+#include "fir_full8s_asm.h"    /* rx_hist_kernel's full-rate filter */
 #include "fir_r2_asm.h"
 #include "fir_r4_asm.h"
 #include "fir_lean_asm.h"      /* WS_LEAN_SLOTS, the streams */
@@ -182,7 +184,19 @@ using namespace pipe;
  * ring (the phase the step started from, four steps per write), then publishes consumed = c + 1.  Shared by rx_fused_pipe_kernel (ring fed by FIR waves) and
  * costas_pipe_kernel (ring fed from already decimated symbols in global memory).
  */
-template <class GM, class SM>   /* SM: Smem, or rx_lean_kernel's control block (ready[], consumed, abort_flag) */
+/* which build of the instruction streams the serial wave runs: costas_asm.h's (VGPRs 100..143) or costas_asm_lo.h's (84..127) */
+struct StreamHi {
+    template <class... A> static __device__ __forceinline__ void ring(A &&...a) { costas_asm_run_ring(a...); }
+    template <class... A> static __device__ __forceinline__ void ring_pair(A &&...a) { costas_asm_run_ring_pair(a...); }
+    template <class... A> static __device__ __forceinline__ unsigned run(A &&...a) { return costas_asm_run(a...); }
+};
+struct StreamLo {
+    template <class... A> static __device__ __forceinline__ void ring(A &&...a) { costas_asm_run_ring_lo(a...); }
+    template <class... A> static __device__ __forceinline__ void ring_pair(A &&...a) { costas_asm_run_ring_pair_lo(a...); }
+    template <class... A> static __device__ __forceinline__ unsigned run(A &&...a) { return costas_asm_run_lo(a...); }
+};
+
+template <class GM, class ST = StreamHi, class SM>   /* SM: Smem, or rx_lean_kernel's control block (ready[], consumed, abort_flag) */
 __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const float2 *dring, float *zring, int G,
                                             int f0, int lane, int nchunks, int *status)
 {
@@ -314,9 +328,9 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
                         if (rp_calls++ == 0) rp_rt1 = rp_real();
 #endif
                         if (pair)
-                            costas_asm_run_ring_pair(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kstop, al, be, fmin_, fmax_, odd, fl, ign);
+                            ST::ring_pair(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kstop, al, be, fmin_, fmax_, odd, fl, ign);
                         else
-                            costas_asm_run_ring(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kstop, al, be, fmin_, fmax_, fl, ign);
+                            ST::ring(ph, fr, d_base, z_base, ready_addr, consumed_addr, ks, kstop, al, be, fmin_, fmax_, fl, ign);
                         ran = true;
 #ifdef QPSK_PIPE_PROFILE
                         rp_tick(rp_in);
@@ -392,7 +406,7 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
                     const unsigned want = __builtin_amdgcn_readfirstlane((unsigned)(cnt - j) / AG);   /* wave-uniform */
                     unsigned left = want;
                     if (!__any(__float_as_uint(fr) == 0x80000000u)) {
-                        left = costas_asm_run(ph, fr, da, za, want, al, be, fmin_, fmax_, fl, ign);
+                        left = ST::run(ph, fr, da, za, want, al, be, fmin_, fmax_, fl, ign);
                         ran = true;
                     }
                     j += AG * (int)(want - left);
@@ -1945,8 +1959,324 @@ int launch_costas_pipe(const FusedArgs &a0, int NF, int *status, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+/* ========================================================================
+ * rx_hist_kernel: the reference's histogram timing mode (qpsk.c:127-191 + 196-212) in ONE pass over the input (round 6).
+ *
+ * Until round 5 histogram mode read the batch twice: timing_scan_kernel (full-rate rrc_fir() + the amplitude-histogram scan, 0.60 ms at
+ * config 2, VALU-bound) for the index, then the receive kernel, which filters the kept phase AGAIN and runs its 2048-step serial chain in
+ * a second launch (0.15 ms).  The index is only known at a frame's END, but it is the same for nearly every frame of a batch and from
+ * batch to batch (every clean frame of one configuration lands on one value), so this kernel takes a GUESS -- the majority index of
+ * the context's previous histogram-mode call, from device memory -- and runs the receive path on it inside the scan kernel's
+ * workgroup, where every filtered sample already is:
+ *   waves 0-3    scan waves, timing_scan_kernel's -- their chain leaves their SIMD two thirds idle, so they also FLUSH the chunks the loop
+ *                has finished (flush_records: sin/cos of the recorded phase, the reference's four products, slicer; 16 lanes per frame);
+ *                at the frame's end they write the true index and, where it differs from the guess, append the frame to the launch's list;
+ *   waves 4-11   FIR waves, timing_scan_kernel's (two frames each, full-rate stream, taps in SGPRs) -- a lane's 8 outputs are
+ *                one symbol, so the guessed phase's pick is one of its accumulators: it goes to the frame's symbol ring row (8 bytes
+ *                per lane and tile; two tiles = one 64-symbol chunk = one hand-over);
+ *   (role 12)    the serial wave of the pipeline kernels (costas_wave: the ring stream in its low-register build, two lanes per
+ *                loop), with all the slack in the world: a chunk arrives every ~18 us and costs it 4-7.
+ * Four waves on a SIMD = 128 VGPRs per wave: the Costas streams come from costas_asm_lo.h (VGPR block at v84..v127); which hardware wave
+ * plays which part is dealt by SIMD (histk::role_of).
+ * The frames on the list are then redone by the fall-back pass (rx_fused_kernel over the list, with the true indices) in a second,
+ * usually empty, launch; a third, one-workgroup launch leaves the batch's majority index as the next call's guess.
+ * Host conditions (rx_hist_shape_ok): CYCLES = 8, whole 64-symbol chunks, a symmetric filter, one loop per frame, no costas_frame[].
+ * ======================================================================== */
+namespace histk {
+constexpr int G = 16, NSCAN = 4, NFIR = 8, UF = 2, QL = 32, R = 8;
+constexpr int TILE = QL * R;          /* 256 outputs = 32 symbols per frame and round */
+constexpr int DRO = 2, PADS = 2, WPOS = TILE + HIST, WSF = 480, PITCH = TILE + 4;
+/* Hardware wave i of a workgroup runs on SIMD i % 4.  The serial wave costs its SIMD 2048 steps x 26 instructions x 4 cycles = 0.09 ms of
+ * vector issue, a scan wave 0.05, a FIR wave 0.25: with the serial wave as a thirteenth wave beside a scan wave and two FIR waves that SIMD
+ * was the kernel's straggler (0.70 ms against timing_scan_kernel's 0.60).  So the roles are dealt by SIMD: SIMD 0 = the serial wave + two
+ * FIR waves and NO scan wave, SIMD 1 = two scan waves + two FIR waves, SIMDs 2, 3 = one scan wave + two FIR waves (0.58 / 0.59 / 0.54 /
+ * 0.54 ms of issue): 14 hardware waves, of which wave 12 (the fourth on SIMD 0) retires at once. */
+constexpr int HW_WAVES = 14;
+constexpr int THREADS = 64 * HW_WAVES;
+__device__ constexpr int role_of(int hw)      /* 0..3: scan wave, 4..11: FIR wave hw - 4, 12: the serial wave, -1: nothing */
+{
+    return hw == 0 ? 12 : hw <= 3 ? hw - 1 : hw <= 11 ? hw : hw == 13 ? 3 : -1;
+}
+__device__ __host__ constexpr int slot_of(int p) { return p + PADS * (p / R); }
+static_assert(slot_of(WPOS - 1) < WSF && WSF % 2 == 0, "window geometry (timing_scan.hip)");
+static_assert(COSTAS_ASM_LO_END_VGPR <= 128, "rx_hist_kernel: four waves on SIMD 0");
+struct Ctl {
+    int ready[NFIR];          /* tiles produced, per FIR wave (scan side) */
+    int consumed[NSCAN];      /* tiles consumed, per scan wave */
+    int flushed[NSCAN];       /* chunks of its four frames a scan wave has turned into symbols (flush_records) */
+    lean::Ctl loop;           /* the receive side: chunks handed over per FIR wave, chunks consumed by the serial wave, the abort flag of both */
+};
+} // namespace histk
+
+__global__ void __launch_bounds__(histk::THREADS)
+rx_hist_kernel(FusedArgs a, int32_t *index_true, const int32_t *hint, int32_t *mis_list, int32_t *mis_count, int *status)
+{
+    using namespace histk;
+    using GM = lean::GeomLean;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Ctl *sm = reinterpret_cast<Ctl *>(smem_raw);
+    float2 *win = reinterpret_cast<float2 *>(smem_raw + sizeof(Ctl));                  /* [G][WSF] */
+    float *ring = reinterpret_cast<float *>(win + (size_t)G * WSF);                    /* [G][DRO][2 planes][PITCH] */
+    unsigned char *rows = reinterpret_cast<unsigned char *>(ring + (size_t)G * DRO * 2 * PITCH);      /* [G][lean::ROW_BYTES]: symbols, records */
+    float2 *dring = reinterpret_cast<float2 *>(rows);
+    float *zring = reinterpret_cast<float *>(rows + lean::Z_OFFSET_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = role_of(__builtin_amdgcn_readfirstlane(tid >> 6));      /* the wave's ROLE (see role_of) */
+    const int f0 = blockIdx.x * G;
+    const int frame_size = a.frame_size, nframes = a.nframes;
+    const int ntiles = frame_size / TILE, nchunks = a.nsym / pipe2::S;
+    const int gi = __builtin_amdgcn_readfirstlane(hint[0]) & 7;      /* the guessed decimation offset of every frame of the launch */
+    int *abortf = &sm->loop.abort_flag;
+
+    if (tid < NFIR) sm->ready[tid] = 0;
+    if (tid < NSCAN) { sm->consumed[tid] = 0; sm->flushed[tid] = 0; }
+    if (tid < MAX_WAVES) sm->loop.ready[tid] = 0;
+    if (tid == 0) { sm->loop.consumed = 0; sm->loop.abort_flag = 0; }
+    __syncthreads();
+
+    if (wave < 0) return;
+    if (wave == NSCAN + NFIR) {
+        /* ================================ the serial wave ======================================================= */
+        costas_wave<GM, StreamLo>(a, &sm->loop, dring, zring, G, f0, lane, nchunks, status);
+        return;
+    }
+    if (wave < NSCAN) {
+        /* ================================ scan wave: frames 4*wave .. 4*wave+3 (timing_scan.hip) ================= */
+        /* ... and the flush of its four frames (flush_records, 16 lanes per frame, four symbols each): the scan's chain leaves this
+         * wave's SIMD two thirds idle, and the chunk the loop has finished is served wherever the wave would otherwise spin or has
+         * just finished a tile.  flushed[wave] tells the FIR waves that a symbol-ring slot may be filled again. */
+        __builtin_amdgcn_s_setprio(3);
+        const int fl = lane >> 4, comp = (lane >> 3) & 1, q = lane & 7;
+        const int g = 4 * wave + fl;
+        const float qf = (float)q;
+        float av = 0.0f, mx = 0.0f;
+        int cum = 0, done = 0;
+        bool ok = true;
+        auto serve_flush = [&]() {
+            const int cons = __builtin_amdgcn_readfirstlane(ld_acquire(&sm->loop.consumed));
+            while (done < cons && done < nchunks) {
+                if (f0 + g < nframes) flush_records<GM, 4>(a, zring, dring, g, f0 + g, lane & 15, done);
+                done++;
+                if (lane == 0) st_release(&sm->flushed[wave], done);
+            }
+        };
+        for (int t = 0; t < ntiles && ok; t++) {
+            /* the tile of this lane's frame comes from FIR wave g / 2; every lane waits for its own producer */
+            int spins = 0;
+            while (!__all(ld_acquire(&sm->ready[g >> 1]) >= t + 1)) {
+                serve_flush();
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > SPIN_LIMIT || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ok = false;
+                    break;
+                }
+            }
+            if (!ok) break;
+            const float4 *row = reinterpret_cast<const float4 *>(ring + ((size_t)(g * DRO + (t % DRO)) * 2 + comp) * PITCH);
+#pragma unroll 4
+            for (int sidx = 0; sidx < TILE / 8; sidx++) {
+                const float4 va = row[2 * sidx], vb = row[2 * sidx + 1];
+                av += fabsf(va.x); av += fabsf(va.y); av += fabsf(va.z); av += fabsf(va.w);      /* qpsk.c:131-136 */
+                av += fabsf(vb.x); av += fabsf(vb.y); av += fabsf(vb.z); av += fabsf(vb.w);
+                av *= 0.125f;                           /* av /= CYCLES (qpsk.c:137-138) */
+                if (av > mx) mx = av;                   /* qpsk.c:140-145 */
+                const float th = (mx * 0.125f) * qf;    /* (max / 8.0f) * q, qpsk.c:147-165 */
+                cum += (av <= th) ? 0 : 1;
+            }
+            if (lane == 0) st_release(&sm->consumed[wave], t + 1);
+            serve_flush();
+        }
+        /* the chunks still in the rings leave as the loop finishes each */
+        while (ok && done < nchunks) {
+            ok = wait_ge(&sm->loop.consumed, done + 1, abortf);
+            if (ok) serve_flush();
+        }
+        if (!ok) {
+            if (lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
+            return;
+        }
+        if (q == 0) cum = frame_size / 8;
+        int h = __shfl_up(cum, 1) - cum;
+        if (q == 0) h = 0;
+        h += __shfl_xor(h, 8);
+        int hmax = 0, best = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int hk = __shfl(h, (lane & ~7) + k);
+            if (hk > hmax) { hmax = hk; best = k; }
+        }
+        if (f0 + g < nframes && comp == 0 && q == 0) {
+            index_true[f0 + g] = best;                  /* qpsk.c:173-180 */
+            if (best != gi) mis_list[atomicAdd(mis_count, 1)] = f0 + g;      /* the guess was wrong for this frame: the fall-back pass redoes it */
+        }
+        return;
+    }
+
+    /* ==================================== FIR wave: frames 2*w, 2*w+1 of the workgroup (timing_scan.hip) ============ */
+    const int w = wave - NSCAN;
+    const int fl = lane / QL, q = lane % QL;
+    const int g = UF * w + fl;
+    const bool fv[UF] = {f0 + UF * w < nframes, f0 + UF * w + 1 < nframes};
+    const float4 *src[UF];
+#pragma unroll
+    for (int ff = 0; ff < UF; ff++)
+        src[ff] = reinterpret_cast<const float4 *>(a.x + (size_t)(fv[ff] ? f0 + UF * w + ff : 0) * a.frame_pitch);
+    float2 *mywin = win + (size_t)(UF * w) * WSF;
+    const unsigned rd_addr = lds_addr(mywin + fl * WSF + (R + PADS) * q);
+    const int p0 = 2 * lane + HIST;
+    float4 hist[UF], pre[UF][2];
+#pragma unroll
+    for (int ff = 0; ff < UF; ff++) hist[ff] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int ff = 0; ff < UF; ff++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float4 v = load_once(&src[ff][(t * TILE + 128 * j + 2 * lane) >> 1]);
+                if (!fv[ff]) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                pre[ff][j] = v;
+            }
+    };
+    prefetch(0);
+    bool ok = true;
+    float2 *drow = dring + (size_t)g * GM::DSTRIDE;
+    for (int t = 0; t < ntiles && ok; t++) {
+        {   /* the two FIR waves of a SIMD stay within a tile of each other (timing_scan.hip) */
+            const int pt = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sm->ready[w ^ 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (pt > t) __builtin_amdgcn_s_setprio(2);
+            else if (pt < t) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(1);
+        }
+#pragma unroll
+        for (int ff = 0; ff < UF; ff++) {
+            float2 *wf = mywin + ff * WSF;
+            if (lane >= 1) *reinterpret_cast<float4 *>(wf + slot_of(p0 - 128)) = hist[ff];
+            *reinterpret_cast<float4 *>(wf + slot_of(p0)) = pre[ff][0];
+            *reinterpret_cast<float4 *>(wf + slot_of(p0 + 128)) = pre[ff][1];
+            hist[ff] = pre[ff][1];
+        }
+        if (t + 1 < ntiles) prefetch(t + 1);
+        v2f a0, a1, a2, a3, a4, a5, a6, a7;
+        fir_full8s_asm(rd_addr, a.taps, a0, a1, a2, a3, a4, a5, a6, a7);
+        if (t >= DRO) ok = wait_ge(&sm->consumed[g >> 2], t - DRO + 1, abortf);
+        const int c = t >> 1;               /* the 64-symbol chunk this tile is half of */
+        /* the symbol ring holds two chunks: chunk c goes where chunk c - 2 was, once the loop is through that one and this frame's scan
+         * wave has flushed it */
+        if (ok && !(t & 1) && c >= DR) ok = wait_ge(&sm->flushed[g >> 2], c - 1, abortf);
+        if (!ok) break;
+        const float2 y0 = fir_gain(make_float2(a0.x, a0.y)), y1 = fir_gain(make_float2(a1.x, a1.y)),
+                     y2 = fir_gain(make_float2(a2.x, a2.y)), y3 = fir_gain(make_float2(a3.x, a3.y)),
+                     y4 = fir_gain(make_float2(a4.x, a4.y)), y5 = fir_gain(make_float2(a5.x, a5.y)),
+                     y6 = fir_gain(make_float2(a6.x, a6.y)), y7 = fir_gain(make_float2(a7.x, a7.y));
+        float *pi = ring + ((size_t)(g * DRO + (t % DRO)) * 2 + 0) * PITCH + R * q;
+        float *pq = pi + PITCH;
+        reinterpret_cast<float4 *>(pi)[0] = make_float4(y0.x, y1.x, y2.x, y3.x);
+        reinterpret_cast<float4 *>(pi)[1] = make_float4(y4.x, y5.x, y6.x, y7.x);
+        reinterpret_cast<float4 *>(pq)[0] = make_float4(y0.y, y1.y, y2.y, y3.y);
+        reinterpret_cast<float4 *>(pq)[1] = make_float4(y4.y, y5.y, y6.y, y7.y);
+        /* qpsk.c:190 on the guessed index: symbol 32 t + q of the frame = this lane's output number gi */
+        float2 pick;
+        switch (gi) {
+        case 0: pick = y0; break;
+        case 1: pick = y1; break;
+        case 2: pick = y2; break;
+        case 3: pick = y3; break;
+        case 4: pick = y4; break;
+        case 5: pick = y5; break;
+        case 6: pick = y6; break;
+        default: pick = y7; break;
+        }
+        drow[(c % DR) * pipe2::S + QL * (t & 1) + q] = pick;
+        if (lane == 0) {
+            st_release(&sm->ready[w], t + 1);
+            if (t & 1) __hip_atomic_store(&sm->loop.ready[w], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      /* behind the release above */
+        }
+    }
+    if (!ok && lane == 0) {
+        __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        report_status(status, STATUS_PIPE_TIMEOUT);
+    }
+}
+
+/* the batch's majority index (first maximum) as the next call's guess, and -- for the host's choice of route next time -- how many of
+ * the batch's frames are NOT on it: h_stats (pinned host memory, one 16-byte store) = {majority index, frames, frames off the majority or
+ * missed by this call's guess (the larger of the two), 0}.  Also resets the miss counter for the next one-pass call. */
+__global__ void __launch_bounds__(1024)
+index_majority_kernel(const int32_t *index, int nframes, int32_t *hint, int32_t *mis_count, int32_t *h_stats)
+{
+    __shared__ int cnt[8];
+    __shared__ int off, best_s;
+    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) off = 0;
+    __syncthreads();
+    int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int f = threadIdx.x; f < nframes; f += 1024) {
+        const int ix = index[f] & 7;
+#pragma unroll
+        for (int k = 0; k < 8; k++) mine[k] += ix == k;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (mine[k]) atomicAdd(&cnt[k], mine[k]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int k = 1; k < 8; k++)
+            if (cnt[k] > cnt[best]) best = k;
+        best_s = best;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int best = best_s;
+        const int offm = nframes - cnt[best];
+        const int missed = mis_count ? mis_count[0] : 0;
+        hint[0] = best;
+        if (mis_count) mis_count[0] = 0;
+        int4 st = make_int4(best, nframes, offm > missed ? offm : missed, 0);
+        *reinterpret_cast<int4 *>(h_stats) = st;
+    }
+    (void)off;
+}
+
+static size_t rx_hist_lds_bytes(void)
+{
+    using namespace histk;
+    return sizeof(Ctl) + sizeof(float2) * (size_t)G * WSF + sizeof(float) * (size_t)G * DRO * 2 * PITCH + (size_t)G * lean::ROW_BYTES;
+}
+
+bool rx_hist_shape_ok(const FusedArgs &a)
+{
+    return a.nbw == 1 && !a.costas && !a.state_in && !a.state_out && a.cycles == C && a.frame_size == a.nsym * C &&
+           a.nsym % pipe2::S == 0 && a.nsym >= 2 * pipe2::S && (a.frame_pitch & 1) == 0 && ((uintptr_t)a.x & 15) == 0 &&
+           a.min_freq < 0.0f && a.max_freq > 0.0f && rx_hist_lds_bytes() <= (size_t)MAX_LDS_BYTES;
+}
+
+int launch_rx_hist(const FusedArgs &a0, int32_t *index_true, const int32_t *hint, int32_t *mis_list, int32_t *mis_count, int *status, hipStream_t s)
+{
+    FusedArgs a = a0;
+    if (!rx_hist_shape_ok(a) || !index_true || !hint || !mis_list || !mis_count) return (int)hipErrorInvalidValue;
+    a.G = histk::G;
+    a.mixed = 2;              /* the serial wave's lane of frame g waits on loop.ready[g / 2]: FIR wave g / 2 */
+    a.share_simd0 = 0;        /* the serial wave at priority 3, like the scan waves: every FIR wave waits for it through the flush */
+    a.lean_pair = a.lean_pair != 0;
+    a.index = nullptr;
+    a.est_tw = nullptr;
+    hipLaunchKernelGGL(rx_hist_kernel, dim3((a.nframes + histk::G - 1) / histk::G), dim3(histk::THREADS), rx_hist_lds_bytes(), s, a, index_true,
+                       hint, mis_list, mis_count, status);
+    return (int)hipGetLastError();
+}
+
+int launch_index_majority(const int32_t *index, int nframes, int32_t *hint, int32_t *mis_count, int32_t *h_stats, hipStream_t s)
+{
+    hipLaunchKernelGGL(index_majority_kernel, dim3(1), dim3(1024), 0, s, index, nframes, hint, mis_count, h_stats);
+    return (int)hipGetLastError();
+}
+
 int prepare_pipe_kernel(void)
 {
+    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(rx_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
+    if (e0 != hipSuccess) return (int)e0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(costas_pipe_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_BYTES);
     if (e != hipSuccess) return (int)e;

@@ -51,7 +51,7 @@ API_SYMBOLS = [
     "qpsk_streams_reset", "qpsk_streams_set_loop_state", "qpsk_streams_get_loop_state", "qpsk_streams_rx_cplx",
     "qpsk_streams_rx_pcm", "qpsk_streams_rx_pcm_host", "qpsk_dev_alloc", "qpsk_dev_free", "qpsk_dev_upload", "qpsk_dev_download",
     "qpsk_selftest_sincos_hash", "qpsk_crc16_batch", "qpsk_interleave_batch", "qpsk_scramble_batch",
-    "qpsk_tx_reset", "qpsk_tx_symbols", "qpsk_test_inject_status", "qpsk_ctx_check",
+    "qpsk_tx_reset", "qpsk_tx_symbols", "qpsk_test_inject_status", "qpsk_test_hist_state", "qpsk_ctx_check",
     "qpsk_multi_create", "qpsk_multi_destroy", "qpsk_multi_shards", "qpsk_multi_load", "qpsk_multi_shard", "qpsk_multi_use_device_input",
     "qpsk_multi_rx_begin", "qpsk_multi_rx_end", "qpsk_multi_set_direct_output", "qpsk_host_alloc", "qpsk_host_free",
 ]
@@ -122,6 +122,7 @@ def load():
     L.qpsk_selftest_sincos_hash.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong)]
     L.qpsk_test_inject_status.argtypes = [vp, i32]
     L.qpsk_ctx_check.argtypes = [vp]
+    L.qpsk_test_hist_state.argtypes = [vp, C.POINTER(i32)]
     L.qpsk_multi_create.argtypes = [C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(Params)]
     L.qpsk_multi_destroy.argtypes = [vp]
     L.qpsk_multi_destroy.restype = None

@@ -397,6 +397,7 @@ def test_lean_kernel_window_staging_by_dma_and_through_registers(oracle, mode):
         want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=ix, threads=min(16, os.cpu_count() or 1))
     import torch
     xd = torch.from_numpy(x).cuda()
+    m.tune(hist_onepass=0)      # this test is about rx_lean_kernel's staging (the one-pass histogram route has its own test)
     for dma in (None, 0):
         m.tune(lean_dma=dma)
         got = m.rx_batch(xd)
@@ -531,6 +532,70 @@ def test_stream_calls_are_all_or_poisoned(oracle):
     for a, b in zip(out, ref):
         for k in ("sym", "freq", "phase"):
             assert bits_equal(cpu(a[k]), cpu(b[k])), k
+
+
+ONEPASS = "rx_hist_kernel (one pass on the guessed index) + rx_fused_kernel (fall-back list)"
+
+
+@pytest.mark.parametrize("F", [4096, 1000, 37])
+def test_histogram_mode_in_one_pass_on_a_guessed_index(oracle, F):
+    """Round 6: histogram timing (the reference's own, qpsk.c:127-191) reads the batch ONCE when the context has a guess -- the majority
+    index of its previous histogram-mode batch: rx_hist_kernel runs the receive path on the guess inside the scan kernel's workgroup,
+    frames whose true index differs go to a list that a fall-back pass redoes.  A modem's first call has no guess (two launches);
+    then (a) the same kind of batch again: the guess holds for the clean frames, the noise / tone frames mixed in (other indices)
+    exercise the fall-back; (b) a batch delayed by three samples: the guess is wrong for EVERY clean frame; (c) the route forced
+    (QPSK_HIST_ONEPASS = 1) on a batch of all indices; (d) the route off.  Every frame of every call against the oracle, index
+    included; ragged batch sizes (not whole 16-frame workgroups) too."""
+    import torch
+    from oracle.pyoracle import TIMING_HIST as TH
+    fs, rs, L = 19200.0, 2400.0, 2048
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TH)
+    nthr = min(16, os.cpu_count() or 1)
+
+    def batch(seed, delay=0, mixed=False):
+        x, _ = make_frames(F, L + 8, 8, m.taps, fs, offset_hz=40.0, base_seed=seed, noise=0.03)
+        x = np.ascontiguousarray(x[:, delay:delay + L])
+        step = 2 if mixed else 29              # (below an eighth of the batch: more misses than that put the route on hold)
+        x[1::step] = random_frames(len(x[1::step]), L, seed=seed + 1)
+        rng, n = np.random.default_rng(seed), np.arange(L)
+        for f in range(3, F, 5 if mixed else 31):
+            z = np.exp(1j * rng.uniform(0.01, 0.5) * n) * rng.uniform(0.2, 3)
+            x[f, :, 0], x[f, :, 1] = z.real, z.imag
+        return x
+
+    def check(x, kernel):
+        want = oracle.rx_batch(x, fs, rs, loop_bw=BW, timing_mode=TH, threads=nthr)
+        got = m.rx_batch(torch.from_numpy(x).cuda())
+        m.sync()
+        if kernel is not None:
+            assert (m.last_kernel() == ONEPASS) == kernel, (m.last_kernel(), kernel)
+        assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz"))
+        return want
+
+    w0 = check(batch(10), False)                     # no guess yet
+    m.tune(hist_onepass=1)                           # the route whenever a guess exists
+    w1 = check(batch(20), True)                      # (a)
+    assert np.bincount(w1["index"], minlength=8).argmax() == np.bincount(w0["index"], minlength=8).argmax()
+    w2 = check(batch(30, delay=3), True)             # (b): every clean frame misses
+    assert np.bincount(w2["index"], minlength=8).argmax() != np.bincount(w1["index"], minlength=8).argmax()
+    check(batch(50, mixed=True), True)               # (c)
+    check(batch(60, delay=5), True)
+    m.tune(hist_onepass=0)
+    check(batch(70), False)                          # (d)
+    # the library's own choice: the route only while every frame of the last batch sat on the batch's majority index
+    m.tune(hist_onepass=None)
+    st = (C.c_int32 * 5)()
+    xc, _ = make_frames(F, L, 8, m.taps, fs, offset_hz=40.0, base_seed=80, noise=0.0)
+    for k in range(3):
+        want = oracle.rx_batch(xc, fs, rs, loop_bw=BW, timing_mode=TH, threads=nthr)
+        m._check(m.L.qpsk_test_hist_state(m.h, st))
+        expect = st[3] > 0 and st[4] == 0                  # what the host will read
+        check(xc, expect)
+        uniform = len(np.unique(want["index"])) == 1
+        m._check(m.L.qpsk_test_hist_state(m.h, st))
+        assert (st[4] == 0) == uniform, (list(st), np.bincount(want["index"], minlength=8))
+    check(batch(90, mixed=True), None)                   # a batch of mixed indices ...
+    check(batch(100), False)                             # ... keeps the next call off the route
 
 
 def test_full_size_config2_bench_stimulus_every_frame(oracle):

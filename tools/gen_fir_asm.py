@@ -121,6 +121,20 @@ def main():
                         adds.append('"v_pk_add_f32 %s, %s, %s\\n\\t"' % (acc[sym], acc[sym], p))
                         np_ += 1
             out += muls + adds
+    # the static guard of tools/gen_lean_asm.py (round 6): behind their four scalar loads the tap SGPRs are live to the end of the stream,
+    # and every register the stream writes must be one it declares as clobbered
+    from gen_lean_asm import written_and_read
+    taps_live = set()
+    for text in out:
+        for line in text.strip('"').split("\\n\\t"):
+            dst, _ = written_and_read(line)
+            if line.startswith("s_load_dwordx16"):
+                taps_live.update(dst)
+                continue
+            for r in dst:
+                assert r not in taps_live, "gen_fir_asm.py: `%s` writes %s, which holds a tap" % (line, r)
+                assert (r[0] == "v" and V0 <= int(r[1:]) < VEND), "gen_fir_asm.py: `%s` writes %s, outside the stream's registers v%d..v%d" % (line, r, V0, VEND - 1)
+    assert len(taps_live) == (64 if SGPR else 0)
     body = "\n        ".join(out)
     clob = ", ".join('"v%d"' % r for r in range(V0, VEND))
     if SGPR:

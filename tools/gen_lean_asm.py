@@ -125,13 +125,85 @@ def slot_of(p):
     return p + 2 * (p // PAD)
 
 
+# ---- the static guard (round 6; VERDICT r5, What's weak 5).  The stream's ~60 named registers are allocated by hand; round 5's first
+# LDS-DMA build took s26 as a temporary while the prologue still kept the taps pointer there, and the GPU reported a memory access fault.
+# Every emitted instruction is therefore parsed for the registers it WRITES, and a write to a register that is declared live -- a
+# long-lived value with its live range: e.protect(regs, why) ... e.release(regs) -- fails the generation (tests/test_generated_headers.py
+# regenerates every header, and checks that the guard catches that very edit).  "rmw" registers may be written by an instruction that
+# also reads them (pointers that advance, counters).
+_NO_DEST = ("s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_sleep", "s_setprio", "s_cmp", "s_bitcmp", "ds_write", "global_store",
+            "buffer_store", "s_endpgm", "s_barrier", "global_load_lds")
+
+
+def _regs_of(tok):
+    """'v[4:7]' -> ['v4'..'v7'], 's26' -> ['s26'], operands of the inline asm ('%[x]'), vcc, exec, m0, literals -> []"""
+    import re
+    tok = tok.strip().lstrip("-|").rstrip("|")
+    m = re.fullmatch(r"([vs])\[(\d+):(\d+)\]", tok)
+    if m:
+        return ["%s%d" % (m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1)]
+    m = re.fullmatch(r"([vs])(\d+)", tok)
+    return ["%s%s" % (m.group(1), m.group(2))] if m else []
+
+
+def written_and_read(line):
+    """(registers the instruction writes, registers it reads) -- first operand = destination, except for the families in _NO_DEST;
+    v_cmp writes vcc (e32) or its first operand (an SGPR pair, e64)"""
+    line = line.split(";")[0].strip()
+    if not line or line.endswith(":"):
+        return [], []
+    parts = line.split(None, 1)
+    mn = parts[0]
+    ops = []
+    if len(parts) > 1:
+        depth, cur = 0, ""
+        for ch in parts[1]:
+            if ch == "[":
+                depth += 1
+            elif ch == "]":
+                depth -= 1
+            if ch == "," and depth == 0:
+                ops.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        ops.append(cur)
+    ops = [o.split()[0] if o.split() else "" for o in ops]       # drop modifiers behind the last operand (op_sel:..., offset:..., nt)
+    if mn.startswith(_NO_DEST):
+        return [], [r for o in ops for r in _regs_of(o)]
+    if mn.startswith("v_cmp"):
+        d = _regs_of(ops[0]) if ops and ops[0].startswith("s") else []
+        return d, [r for o in ops[1 if d else 0:] for r in _regs_of(o)]
+    dst = _regs_of(ops[0]) if ops else []
+    src = [r for o in ops[1:] for r in _regs_of(o)]
+    if mn.startswith(("v_fmac", "v_mac", "v_pk_fmac")):          # the destination is an addend too
+        src += dst
+    return dst, src
+
+
 class Emit:
     def __init__(self):
         self.lines = []
         self.nlabel = 0
+        self.live = {}          # register -> (why, rmw)
+
+    def protect(self, regs, why, rmw=False):
+        for r in regs:
+            self.live[r] = (why, rmw)
+
+    def release(self, regs):
+        for r in regs:
+            self.live.pop(r, None)
 
     def __call__(self, fmt, *a):
-        self.lines.append((fmt % a) if a else fmt)
+        line = (fmt % a) if a else fmt
+        dst, src = written_and_read(line)
+        for r in dst:
+            if r in self.live:
+                why, rmw = self.live[r]
+                if not (rmw and r in src):
+                    raise AssertionError("gen_lean_asm.py: `%s` writes %s, which is live: %s" % (line, r, why))
+        self.lines.append(line)
 
     def label(self, stem):
         self.nlabel += 1
@@ -229,8 +301,11 @@ def stage_frame(e, ui, ff):
     hist = HIST + 8 * ui + 4 * ff
     if ABLATE == "stage":      # no window writes at all: the filter reads whatever the LDS holds (only the history registers move on)
         r = PRE + 16 * ff + 12
+        held = {k: e.live[k] for k in ("v%d" % x for x in range(hist, hist + 4)) if k in e.live}
+        e.release(list(held))
         e("v_mov_b64 %s, %s", vp(hist), vp(r))
         e("v_mov_b64 %s, %s", vp(hist + 2), vp(r + 2))
+        e.live.update(held)
         return
     odd, done = e.label("odd"), e.label("stg")
     e("s_bfe_u32 s%d, s%d, 0x4%04x", ST0, SIX, sh)             # the frame's decimation offset
@@ -277,8 +352,11 @@ def stage_frame(e, ui, ff):
             e("ds_write_b64 %s, %s offset:%d", wr1, vp(r + 2), (j + 1) * BLK_BYTES)
     e.place(done)
     r = PRE + 16 * ff + 12
+    held = {k: e.live[k] for k in ("v%d" % x for x in range(hist, hist + 4)) if k in e.live}
+    e.release(list(held))                          # the one legitimate writer of the history registers
     e("v_mov_b64 %s, %s", vp(hist), vp(r))
     e("v_mov_b64 %s, %s", vp(hist + 2), vp(r + 2))
+    e.live.update(held)
 
 
 def loads(e, u):
@@ -521,6 +599,12 @@ def block(nuw, packed=True):
     e("v_readfirstlane_b32 s%d, v%d", SIX, PRE + 13)
     e("v_readfirstlane_b32 s%d, v%d", ST0, PRE + 16)
     e("v_readfirstlane_b32 s%d, v%d", ST1, PRE + 17)
+    # live from here (the static guard, see Emit): the parameters of the whole stream, and -- until the four tap loads below -- the taps
+    # pointer in s26:27, which the loads of the first unit, issued in between, must leave alone (round 5's fault)
+    e.protect(["s%d" % r for r in range(SRC, SRC + 8)], "source pointers (advance by a chunk per unit: read-modify-write only)", rmw=True)
+    e.protect(["s%d" % r for r in range(SYMB, SYMB + 4)], "symbol store bases (advance by a chunk per flush: read-modify-write only)", rmw=True)
+    e.protect(["s%d" % SN, "s%d" % SIX], "chunk count / decimation offsets")
+    e.protect(["s%d" % ST0, "s%d" % ST1], "the taps pointer, until the s_load_dwordx16 of the taps have been issued")
     if DMA:         # per-lane DMA source offsets and the DMA regions' LDS addresses: a table the kernel left in the (still unused) window
         e("v_mov_b32_e32 v%d, m0", DMA_M0)
         for k in range(2 * nuw):
@@ -531,17 +615,25 @@ def block(nuw, packed=True):
         if TWOWIN:
             e("v_add_u32_e32 v%d, 0x%x, %%[wlim]", DMA_WLIM1, WOFF)
             e("v_add_u32_e32 v%d, 0x%x, %%[wpad]", DMA_WPAD1, WOFF)
+        e.protect(["v%d" % (DMA_OFF[k] + j) for k in range(2 * nuw) for j in range(4)] + ["v%d" % (DMA_BASE + k) for k in range(2 * nuw)] +
+                  ["v%d" % DMA_M0] + (["v%d" % DMA_WLIM1, "v%d" % DMA_WPAD1] if TWOWIN else []),
+                  "the LDS-DMA tables (per-lane source offsets, DMA regions), the compiler's m0, unit 1's window limits")
     loads(e, 0)                 # the first unit's samples at once: their HBM latency covers the tap loads and the set-up below
     for i in range(4):
         e("s_load_dwordx16 s[%d:%d], %s, 0x%x", TAP0 + 16 * i, TAP0 + 16 * i + 15, sp(ST0), 64 * i)
+    e.release(["s%d" % ST0, "s%d" % ST1])
+    e.protect(["s%d" % r for r in range(TAP0, TAP0 + 64)], "the 64 distinct taps")
     for reg, bits in CONSTS.items():
         e("v_mov_b32_e32 v%d, 0x%08x", reg, bits & 0xffffffff)
         e("v_mov_b32_e32 v%d, 0x%08x", reg + 1, bits >> 32)
     e("v_mov_b32_e32 v%d, 0x%08x", TMP, ROT45)
+    e.protect(["v%d" % r for r in range(CONST, CONST + 22)] + ["v%d" % TMP], "the eleven fp64 constants, ROT45")
     for r in range(HIST, HIST + 16):
         e("v_mov_b32_e32 v%d, 0", r)                           # fresh delay lines (qpsk.c:37)
+    e.protect(["v%d" % r for r in range(HIST, HIST + 8 * nuw)], "the delay lines' history (rewritten only by stage_frame, from the block just staged)")
     e("s_mov_b32 s%d, 0", SC)
     e("s_mov_b32 s%d, 0", SFL)
+    e.protect(["s%d" % SC], "the chunk counter (read-modify-write only)", rmw=True)
     e("s_waitcnt lgkmcnt(0)")                                  # the taps
     if PROFILE and not ABLATE:
         for k in range(NPROF):
