@@ -118,6 +118,17 @@ def batch_case(oracle, modem_factory, seed, max_samples=6_000_000):
         g = got[k].cpu().numpy()
         if not bits_equal(g, want[k].astype(g.dtype)):
             bad.append(k)
+    if mode == TIMING_HIST and call == "plain" and not bad:
+        # round 6: a histogram-mode context's SECOND call may take the one-pass route (rx_hist_kernel on the first batch's majority index,
+        # a fall-back pass over the frames it misses); forced here whatever the batch's mix of indices, where the shape allows it
+        m.tune(hist_onepass=1)
+        got = m.rx_batch(x)
+        m.sync()
+        desc += " | again: " + m.last_kernel().split(" (")[0]
+        for k in keys:
+            g = got[k].cpu().numpy()
+            if not bits_equal(g, want[k].astype(g.dtype)):
+                bad.append(k + " (second call)")
     m.close()
     return desc, bad
 

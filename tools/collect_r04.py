@@ -80,7 +80,7 @@ def main():
         if ok(n) and os.path.exists(p) and os.path.getsize(p) > 0:
             shutil.copy(p, os.path.join(OUT, "%s_%s.json" % (TAG, n)))
     for sub, name in (("prof_bench", "bench"), ("prof_bench20", "bench_config2_driver_style"), ("prof_config3", "config3"),
-                      ("prof_fft_sep", "fft_estimator_kernel"), ("prof_streams", "streams"), ("prof_fir", "fir")):
+                      ("prof_fft_sep", "fft_estimator_kernel"), ("prof_streams", "streams"), ("prof_fir", "fir"), ("prof_hist1", "hist_one_pass")):
         copy_stats(sub, name)
 
     # ---- HBM traffic per launch and kernel, per workload
@@ -88,7 +88,7 @@ def main():
              "median over the launches of a pass; reads = FETCH_SIZE x 2 x 1024 B (gfx950 counts a 128-byte request of a 16-byte-per-lane streaming read as 64 B,",
              "MI355X_MICROARCH.md), writes = WRITE_SIZE x 1024 B).  Algorithmic bytes of a 4096 x 16384 batch: 536,870,912 (8 B per input sample).", ""]
     shapes = {}
-    for w, frames in (("config2", 4096), ("8192", 8192), ("config3", 4096), ("hist", 4096), ("fft_est", 4096), ("scan", 4096), ("fir", 4096), ("streams", 4096)):
+    for w, frames in (("config2", 4096), ("8192", 8192), ("config3", 4096), ("hist", 4096), ("hist1", 4096), ("fft_est", 4096), ("scan", 4096), ("fir", 4096), ("streams", 4096)):
         fc, wc = counters("pmc_fetch_" + w), counters("pmc_write_" + w)
         for k in sorted(set(fc) | set(wc)):
             fv, wv = fc.get(k, {}).get("FETCH_SIZE"), wc.get(k, {}).get("WRITE_SIZE")
