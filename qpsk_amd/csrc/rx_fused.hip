@@ -1858,7 +1858,7 @@ static LeanGeometry lean_geometry(const FusedArgs &a, int G, unsigned long long 
      * after it), at most MAX_FPW frames per wave, estimator windows in the frame windows, taps + indices behind the rows */
     {
         /* twelve hardware waves (three per SIMD: the kernel's register budget) share the workgroup's frames: 0.1654 ms against 0.1692 with
-         * eight at config 3, launches interleaved in one process (profiles/r06_config3.txt) */
+         * eight at config 3, launches interleaved in one process (profiles/r06_config3_estimator_waves.txt) */
         const int want = a.est_waves > 0 ? a.est_waves : 12;
         g.hw_est = g.hw < want ? want : g.hw;
         if (g.hw_est > MAX_THREADS / 64) g.hw_est = MAX_THREADS / 64;

@@ -77,7 +77,9 @@ def test_bench_shard_key_is_wired_to_config_2():
     code), without touching `value` / `config` / `roofline`"""
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'res["shard_8192"] = sh' in src and "(F, L) == (FRAMES_1GPU, 16384) and not args.no_shard" in src
-    assert src.count("timed_region(") == 5          # the definition and its uses: config 2, the timing modes, the AWGN variant, the shard
+    assert src.count("timed_region(") == 6          # the definition and its uses: config 2, the timing modes, histogram mode's two-launch route, the AWGN variant, the shard
+    # round 6: burst and sustained (VERDICT r5 item 6), the result gather through the C host layer (item 5)
+    assert '"sustained_ms_per_step"' in src and 'sh["sustained_ms_per_step"]' in src and 'res["gather"]' in src and "kernel_ms_event_pair_per_launch\"]" not in src
     # BASELINE configs[2] (FFT timing estimate in front) and the reference's histogram mode ride along the same way
     assert 'res[key] = ent' in src and '("config3", qpsk_amd.TIMING_FFT' in src and '("hist", qpsk_amd.TIMING_HIST' in src
 
