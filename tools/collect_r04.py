@@ -105,6 +105,11 @@ def main():
                     "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane streaming reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is",
                     "read_bytes": rb, "write_bytes": wb, "hbm_bytes_per_launch": rb + wb, "algorithmic_read_bytes": int(alg),
                     "source": "profiles/%s_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over tools/loop_kernel.py, median of %d launches)" % (TAG, len(fv))}
+    if any(ln.startswith("hist1") for ln in lines):
+        lines += ["", "hist  = histogram mode as the counter pass runs it: its 12 calls are enqueued before the first one's statistics have reached the host, so every",
+                  "        call takes the two-launch route (timing_scan_kernel, then the receive kernel: the batch read twice);",
+                  "hist1 = the same pass with QPSK_HIST_ONEPASS=1: from the second call on rx_hist_kernel reads the batch ONCE (round 6), the fall-back pass",
+                  "        (rx_fused_kernel over the list of frames the guess missed) and the majority kernel read next to nothing."]
     if len(lines) > 4:
         open(os.path.join(OUT, "%s_hbm_traffic.txt" % TAG), "w").write("\n".join(lines) + "\n")
         print("\n".join(lines[4:]))
