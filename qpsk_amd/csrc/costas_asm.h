@@ -1,6 +1,7 @@
 /*
  * costas_asm.h -- the Costas recurrence (qpsk.c:197-207 + costas_loop.c:44-74) as a hand-scheduled gfx950
- * instruction stream, for the serial wave of rx_fused_pipe_kernel.
+ * instruction stream, for the serial wave of the pipeline kernels (rx_lean_kernel, rx_fused_pipe_kernel, rx_pipe2_kernel,
+ * costas_pipe_kernel, stream_block_kernel; rx_hist_kernel runs the generated low-register copy, costas_asm_lo.h).
  *
  * Why assembly: the recurrence runs in ONE wave per workgroup and that wave is strictly in order.  Measured
  * on MI355X (timing-only variants of this stream inside the kernel in round 1, tools/ab_libs.py; the stream alone
@@ -9,7 +10,10 @@
  * cycles per dependent instruction" of round 1's notes came from one-instruction asm statements, which the compiler
  * pads with s_nop), ~16-21 per LDS instruction almost regardless of its size (16 -> 12 -> 4 bytes per step: -2.4 %,
  * then -1 %; one write per 16 steps instead of one per step: -8 %), 13-15 for the per-step wrap test's branch with
- * the wraps it takes.  The compiler's version of the step ran ~355 cycles.  What this stream does about it:
+ * the wraps it takes.  (Round 6, profiles/r06_step_cost.txt: the price is per INSTRUCTION, ~4.5 cycles, not per byte -- 4-byte
+ * encodings of three fp64 operations changed nothing -- and a branch waits for the compare that feeds it: 165.6 cycles per step with the
+ * wrap branch right behind its test, 146.1 nine instructions on.)  The compiler's version of the step ran ~355 cycles.  What this stream
+ * does about it:
  *   - 28 VALU instructions per step (26 in the paired-lane form below), as few of them 8-byte encodings as the ISA allows: the
  *     range reduction is v_mul_f64 + v_rndne_f64 (VOP1) + v_fmac_f64 (VOP2: gfx90a on) in place on the argument, the sine's last
  *     stage a v_fmac_f64 in place on the reduced argument (round 6; n = rndne(fl(x 2/pi)) equals the magic-number rounding
@@ -18,11 +22,11 @@
  *     the rotation from it, bit for bit the same operations): four steps' phases sit in v140..v143 and go to LDS
  *     in one ds_write_b128, so the wave issues 0.75 LDS instructions per step (two symbols per ds_read_b128,
  *     fetched two steps ahead into alternating register sets) instead of 1.5;
- *   - what nothing in step k+1 waits for -- step k's frequency clamp and exact-zero test, the 2*pi test of the
- *     phase it produced -- is issued in the empty slots between the five dependent fp64 operations of step
- *     k+1's head;
- *   - the 2*pi wrap is out of line AND late: step k+1 starts from the unwrapped phase, the branch sits at the end
- *     of the head, and the rare wrap block corrects the phase where it stands and redoes the head;
+ *   - what nothing in step k+1 waits for -- step k's frequency clamp and exact-zero test -- is issued between the dependent fp64
+ *     operations of step k+1's head (one-lane form) or where a DPP read needs two wait states (paired form);
+ *   - the 2*pi wrap is out of line AND late: step k+1 starts from the unwrapped phase; its 2*pi test is the step's FIRST instruction and
+ *     the branch stands behind the head and the first rows of the polynomial chains (round 6), and the rare wrap block corrects the phase
+ *     where it stands and redoes what stood in front of the branch;
  *   - groups of 16 steps: the per-group bookkeeping (state snapshot, flag test, taken loop branch) costs
  *     ~60 cycles;
  *   - the exact-zero test of the detector input is a running min over the group; with zeros out of the way

@@ -1826,7 +1826,7 @@ struct LeanGeometry {
     bool ok;          /* layout and LDS are valid for G */
     bool est_ok;      /* ... and the in-launch FFT timing estimate fits beside them */
     int units, nwin, hw;      /* two-frame units, frame windows, hardware waves launched WITHOUT the estimate */
-    int hw_est, nwe;          /* hardware waves launched WITH it (at least eight), and how many of them estimate */
+    int hw_est, nwe;          /* hardware waves launched WITH it (twelve unless the caller says otherwise), and how many of them estimate */
     bool twowin, pair;
     size_t lds, lds_est;
 };
@@ -1854,7 +1854,7 @@ static LeanGeometry lean_geometry(const FusedArgs &a, int G, unsigned long long 
      * workgroup, every lane of the wave busy, the board at its power limit) 0.2531 -> 0.2541-0.2545: not there] */
     g.pair = (a.lean_pair == 2 && 2 * G <= 64) || (a.lean_pair == 1 && G <= 16) || (a.lean_pair == 3 && G <= 24);
     g.lds = lean_lds_bytes(G, g.nwin);
-    /* the FFT timing estimate inside the launch: at least eight hardware waves share the workgroup's frames (waves without a unit retire
+    /* the FFT timing estimate inside the launch: twelve hardware waves share the workgroup's frames (waves without a unit retire
      * after it), at most MAX_FPW frames per wave, estimator windows in the frame windows, taps + indices behind the rows */
     {
         /* twelve hardware waves (three per SIMD: the kernel's register budget) share the workgroup's frames: 0.1654 ms against 0.1692 with
