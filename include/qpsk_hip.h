@@ -333,7 +333,8 @@ int qpsk_scramble_batch(qpsk_ctx *ctx, uint8_t *d_sym, int npackets, int nsym);
  * frame returns 2056 bytes: 16.1 MiB per 8192-frame step, ~0.3 ms over PCIe
  * Gen5 x16 -- as long as the step's kernel; the copy-back, not the kernel,
  * bounds a host that wants every step's symbols (examples/shard_devices.c,
- * bench.py `gather`).
+ * bench.py `gather`).  One caller thread at a time per qpsk_multi (the
+ * object runs its own thread per shard; its entry points are not reentrant).
  * ------------------------------------------------------------------------- */
 typedef struct qpsk_multi qpsk_multi;
 int qpsk_multi_create(qpsk_multi **out, const int *devices, int ndev, const qpsk_params *p);

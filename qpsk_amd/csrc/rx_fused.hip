@@ -2206,9 +2206,7 @@ __global__ void __launch_bounds__(1024)
 index_majority_kernel(const int32_t *index, int nframes, int32_t *hint, int32_t *mis_count, int32_t *h_stats)
 {
     __shared__ int cnt[8];
-    __shared__ int off, best_s;
     if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) off = 0;
     __syncthreads();
     int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int f = threadIdx.x; f < nframes; f += 1024) {
@@ -2224,11 +2222,6 @@ index_majority_kernel(const int32_t *index, int nframes, int32_t *hint, int32_t 
         int best = 0;
         for (int k = 1; k < 8; k++)
             if (cnt[k] > cnt[best]) best = k;
-        best_s = best;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int best = best_s;
         const int offm = nframes - cnt[best];
         const int missed = mis_count ? mis_count[0] : 0;
         hint[0] = best;
@@ -2236,7 +2229,6 @@ index_majority_kernel(const int32_t *index, int nframes, int32_t *hint, int32_t 
         int4 st = make_int4(best, nframes, offm > missed ? offm : missed, 0);
         *reinterpret_cast<int4 *>(h_stats) = st;
     }
-    (void)off;
 }
 
 static size_t rx_hist_lds_bytes(void)
