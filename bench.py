@@ -651,16 +651,27 @@ def main():
             none3 = (None, None, None)
             overlapped((none3, none3))
             g_direct = overlapped((none3, none3))
+            # ... and with the symbols packed four to a byte on the device (qpsk_pack_symbols: 4 MiB instead of 16 per step)
+            mj.set_direct(0); mj.set_direct(1)
+            mj.set_packed(True)
+            q_a, q_b = mj.pinned_outputs(), mj.pinned_outputs()
+            mj.set_direct(0, *q_a); mj.set_direct(1, *q_b)
+            overlapped((none3, none3))
+            g_packed = overlapped((none3, none3))
+            packed_ok = bool(np.array_equal(mj.unpack(q_a[0]), o_a[0]) and np.array_equal(q_b[0], q_a[0]))
             same = bool(np.array_equal(p_a[0], o_a[0]) and np.array_equal(p_b[0], o_b[0]) and np.array_equal(o_a[0], outs2[0].cpu().numpy()) and
                         np.array_equal(p_a[1].view(np.uint32), outs2[1].cpu().numpy().view(np.uint32)))
             gbytes = F2 * (L // 8) + 8 * F2
             res["gather"] = {"frames": F2, "frame_size": L, "steps": kg, "bytes_per_step": gbytes,
                              "kernel_ms_per_step": dt2 / args.steps * 1e3,
                              "ms_per_step_serial": g_serial, "ms_per_step_overlapped": g_over, "ms_per_step_overlapped_direct": g_direct,
+                             "ms_per_step_overlapped_direct_packed": g_packed, "bytes_per_step_packed": F2 * (L // 32) + 8 * F2,
+                             "packed_equals_unpacked": packed_ok,
                              "pcie_bound_ms": gbytes / 63e9 * 1e3, "pcie_bound_assumes": "PCIe Gen5 x16, 63 GB/s",
                              "gathered_equals_device_results": same,
                              "what": "qpsk_multi_rx_begin/end (one shard on this GPU): kernel + copy-back of symbols, freq, phase to host memory; "
-                                     "serial / overlapped through pinned staging with a concatenating memcpy, overlapped_direct by DMA into the caller's pinned arrays"}
+                                     "serial / overlapped through pinned staging with a concatenating memcpy, overlapped_direct by DMA into the caller's pinned arrays, "
+                                     "overlapped_direct_packed with the symbols four to a byte (qpsk_multi_set_packed)"}
             mj.close()
         res["shard_8192"] = sh
     if world == 1 and (args.frames, L) == (FRAMES_1GPU, 16384) and not args.no_config5:

@@ -349,6 +349,12 @@ int qpsk_multi_use_device_input(qpsk_multi *mj, int r, const float *d_in);
  * step: ~1.4 ms of one host core, five times the kernel).  The arrays must be page-locked (qpsk_host_alloc) and stay valid while the
  * slot is used; all NULL = back to staging. */
 int qpsk_multi_set_direct_output(qpsk_multi *mj, int slot, uint8_t *h_sym, float *h_freq, float *h_phase);
+/* Packed mode: the symbols come back FOUR PER BYTE -- h_sym rows of ceil(nsym / 4) bytes, byte k = sym[4k] | sym[4k+1] << 2 | sym[4k+2] << 4 |
+ * sym[4k+3] << 6 (qpsk_pack_symbols on the device, 16 MiB -> 4 MiB per 8192-frame step): the copy-back drops under the kernel's time and
+ * a gathered step costs what the kernel costs.  qpsk_unpack_symbols_host() gives a byte per symbol again where a caller wants it. */
+int qpsk_multi_set_packed(qpsk_multi *mj, int on);
+int qpsk_pack_symbols(qpsk_ctx *ctx, const uint8_t *d_sym, long long nrows, int nsym, uint8_t *d_packed);
+int qpsk_unpack_symbols_host(const uint8_t *h_packed, long long nrows, int nsym, uint8_t *h_sym);
 int qpsk_host_alloc(void **h_ptr, size_t bytes);      /* page-locked host memory, usable from every device */
 int qpsk_host_free(void *h_ptr);
 int qpsk_multi_rx_begin(qpsk_multi *mj, int slot);

@@ -417,6 +417,30 @@ int qpsk_ctx_sync(qpsk_ctx *c)
     return check_status(c);
 }
 
+/* four 2-bit symbols per byte (bitstages.hip): what a host that gathers every step copies back instead of a byte per symbol */
+int qpsk_pack_symbols(qpsk_ctx *c, const uint8_t *d_sym, long long nrows, int nsym, uint8_t *d_packed)
+{
+    if (!c || !d_sym || !d_packed || nrows < 0 || nsym <= 0) return fail(QPSK_ERR_ARG, "qpsk_pack_symbols: bad argument");
+    if (bind(c)) return QPSK_ERR_HIP;
+    if ((nsym & 15) == 0 && (((uintptr_t)d_sym & 15) || ((uintptr_t)d_packed & 3)))
+        return fail(QPSK_ERR_ARG, "qpsk_pack_symbols: d_sym must be 16-byte and d_packed 4-byte aligned");
+    KERNEL_TRY(launch_pack_dibits(d_sym, d_packed, (size_t)nrows, nsym, c->stream));
+    return QPSK_OK;
+}
+
+/* the host side of it: plain C, a format conversion for callers that want a byte per symbol again */
+int qpsk_unpack_symbols_host(const uint8_t *h_packed, long long nrows, int nsym, uint8_t *h_sym)
+{
+    if (!h_packed || !h_sym || nrows < 0 || nsym <= 0) return fail(QPSK_ERR_ARG, "qpsk_unpack_symbols_host: bad argument");
+    const size_t pb = (size_t)(nsym + 3) / 4;
+    for (long long r = 0; r < nrows; r++) {
+        const uint8_t *p = h_packed + (size_t)r * pb;
+        uint8_t *o = h_sym + (size_t)r * (size_t)nsym;
+        for (int i = 0; i < nsym; i++) o[i] = (uint8_t)((p[i >> 2] >> (2 * (i & 3))) & 3u);
+    }
+    return QPSK_OK;
+}
+
 /* the status word WITHOUT a synchronisation: what the kernels completed so far have flagged (multi.cpp looks at it behind a result
  * slot's copy event, while the next step may already be running on the compute stream) */
 int qpsk_ctx_check(qpsk_ctx *c)

@@ -61,6 +61,40 @@ scramble_kernel(uint8_t *sym, const uint8_t *__restrict__ keystream, int npacket
     sym[i] = (uint8_t)(sym[i] ^ k);
 }
 
+/* Four 2-bit symbols per byte (round 6): a receive step's symbols are 1 byte each by the API (the value of qpsk_demod()'s two bits,
+ * qpsk.c:77-78), but carry 2 bits -- and the copy-back over PCIe, not the kernel, bounds a host that gathers every step.
+ * Row r of nsym symbols -> row r of ceil(nsym / 4) bytes: byte k = sym[4k] | sym[4k+1] << 2 | sym[4k+2] << 4 | sym[4k+3] << 6. */
+__global__ void __launch_bounds__(256)
+pack_dibits_kernel(const uint8_t *__restrict__ sym, uint8_t *__restrict__ packed, size_t nrows, int nsym)
+{
+    const int pb = (nsym + 3) / 4;
+    if ((nsym & 15) == 0) {      /* 16 symbols in, 4 bytes out per thread */
+        const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, per_row = (size_t)(nsym >> 4);
+        if (i >= nrows * per_row) return;
+        const uint4 v = reinterpret_cast<const uint4 *>(sym)[i];
+        auto pk = [](unsigned w) { return (w & 3u) | ((w >> 6) & 0xcu) | ((w >> 12) & 0x30u) | ((w >> 18) & 0xc0u); };
+        reinterpret_cast<uint32_t *>(packed)[i] = pk(v.x) | (pk(v.y) << 8) | (pk(v.z) << 16) | (pk(v.w) << 24);
+        return;
+    }
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrows * (size_t)pb) return;
+    const size_t r = i / (size_t)pb;
+    const int k = (int)(i - r * (size_t)pb);
+    const uint8_t *row = sym + r * (size_t)nsym;
+    unsigned b = 0;
+    for (int j = 0; j < 4; j++)
+        if (4 * k + j < nsym) b |= (unsigned)(row[4 * k + j] & 3u) << (2 * j);
+    packed[i] = (uint8_t)b;
+}
+
+int launch_pack_dibits(const uint8_t *sym, uint8_t *packed, size_t nrows, int nsym, hipStream_t s)
+{
+    const size_t n = (nsym & 15) == 0 ? nrows * (size_t)(nsym >> 4) : nrows * (size_t)((nsym + 3) / 4);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_dibits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sym, packed, nrows, nsym);
+    return (int)hipGetLastError();
+}
+
 int launch_crc16(const uint8_t *data, int npackets, int nbytes, uint16_t *crc, hipStream_t s)
 {
     hipLaunchKernelGGL(crc16_kernel, dim3((npackets + 255) / 256), dim3(256), 0, s, data, npackets, nbytes, crc);

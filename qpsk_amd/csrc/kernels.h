@@ -205,6 +205,7 @@ int launch_carrier_broadcast(const float *cstate, float *mixer, int nstreams, hi
 int launch_crc16(const uint8_t *data, int npackets, int nbytes, uint16_t *crc, hipStream_t s);
 int launch_interleave(uint8_t *data, int npackets, int nbytes, unsigned b, int dir, hipStream_t s);
 int launch_scramble(uint8_t *sym, const uint8_t *keystream, int npackets, int nsym, hipStream_t s);
+int launch_pack_dibits(const uint8_t *sym, uint8_t *packed, size_t nrows, int nsym, hipStream_t s);      /* sym 16-byte aligned when nsym % 16 == 0 */
 /* txchain.hip */
 int tx_history_symbols(void);          /* symbols of state per transmitter (uint8 each, 4 = none yet) */
 int launch_tx_shape(const uint8_t *sym, uint8_t *hist, const float *taps, float *sig, int nstreams, int nsym,

@@ -38,6 +38,7 @@ struct Shard {
     float *d_in = nullptr;            /* [count][frame_size][2]; owned unless `borrowed` */
     bool borrowed = false;
     uint8_t *d_sym[2] = {nullptr, nullptr};
+    uint8_t *d_pack[2] = {nullptr, nullptr};      /* packed mode: four symbols per byte, what is copied back instead of d_sym */
     float *d_fp[2] = {nullptr, nullptr};          /* freq [count] then phase [count] */
     uint8_t *h_sym[2] = {nullptr, nullptr};       /* pinned */
     float *h_fp[2] = {nullptr, nullptr};
@@ -64,6 +65,8 @@ struct Shard {
 struct qpsk_multi {
     qpsk_params prm{};
     int nsym = 0;
+    bool packed = false;      /* h_sym rows are ceil(nsym / 4) bytes (qpsk_multi_set_packed) */
+    size_t row_bytes() const { return packed ? (size_t)(nsym + 3) / 4 : (size_t)nsym; }
     long long total = 0;
     std::vector<Shard *> shards;
 };
@@ -95,18 +98,27 @@ int shard_begin(qpsk_multi *mj, Shard *s, int slot)
         snprintf(s->err, sizeof(s->err), "device %d: %s", s->device, qpsk_last_error());
         return rc;
     }
+    const uint8_t *d_out = s->d_sym[slot];
+    const size_t rb = mj->row_bytes();
+    if (mj->packed) {
+        const int rp = qpsk_pack_symbols(s->ctx, s->d_sym[slot], s->count, mj->nsym, s->d_pack[slot]);
+        if (rp) {
+            snprintf(s->err, sizeof(s->err), "device %d: %s", s->device, qpsk_last_error());
+            return rp;
+        }
+        d_out = s->d_pack[slot];
+    }
     M_HIP(s, hipEventRecord(s->done[slot], s->compute));
     M_HIP(s, hipStreamWaitEvent(s->copy, s->done[slot], 0));
     if (s->dir_sym[slot] || s->dir_freq[slot] || s->dir_phase[slot]) {
         if (s->dir_sym[slot])
-            M_HIP(s, hipMemcpyAsync(s->dir_sym[slot] + (size_t)s->first * (size_t)mj->nsym, s->d_sym[slot], (size_t)s->count * (size_t)mj->nsym,
-                                    hipMemcpyDeviceToHost, s->copy));
+            M_HIP(s, hipMemcpyAsync(s->dir_sym[slot] + (size_t)s->first * rb, d_out, (size_t)s->count * rb, hipMemcpyDeviceToHost, s->copy));
         if (s->dir_freq[slot])
             M_HIP(s, hipMemcpyAsync(s->dir_freq[slot] + s->first, s->d_fp[slot], sizeof(float) * (size_t)s->count, hipMemcpyDeviceToHost, s->copy));
         if (s->dir_phase[slot])
             M_HIP(s, hipMemcpyAsync(s->dir_phase[slot] + s->first, s->d_fp[slot] + s->count, sizeof(float) * (size_t)s->count, hipMemcpyDeviceToHost, s->copy));
     } else {
-        M_HIP(s, hipMemcpyAsync(s->h_sym[slot], s->d_sym[slot], (size_t)s->count * (size_t)mj->nsym, hipMemcpyDeviceToHost, s->copy));
+        M_HIP(s, hipMemcpyAsync(s->h_sym[slot], d_out, (size_t)s->count * rb, hipMemcpyDeviceToHost, s->copy));
         M_HIP(s, hipMemcpyAsync(s->h_fp[slot], s->d_fp[slot], sizeof(float) * 2 * (size_t)s->count, hipMemcpyDeviceToHost, s->copy));
     }
     M_HIP(s, hipEventRecord(s->copied[slot], s->copy));
@@ -131,7 +143,7 @@ int shard_end(qpsk_multi *mj, Shard *s, int slot)
         return rc;
     }
     if (s->dir_sym[slot] || s->dir_freq[slot] || s->dir_phase[slot]) return QPSK_OK;      /* already where the caller wants it */
-    if (s->out_sym) memcpy(s->out_sym + (size_t)s->first * (size_t)mj->nsym, s->h_sym[slot], (size_t)s->count * (size_t)mj->nsym);
+    if (s->out_sym) memcpy(s->out_sym + (size_t)s->first * mj->row_bytes(), s->h_sym[slot], (size_t)s->count * mj->row_bytes());
     if (s->out_freq) memcpy(s->out_freq + s->first, s->h_fp[slot], sizeof(float) * (size_t)s->count);
     if (s->out_phase) memcpy(s->out_phase + s->first, s->h_fp[slot] + s->count, sizeof(float) * (size_t)s->count);
     return QPSK_OK;
@@ -194,6 +206,8 @@ void free_shard_buffers(Shard *s)
     s->borrowed = false;
     for (int k = 0; k < 2; k++) {
         if (s->d_sym[k]) hipFree(s->d_sym[k]);
+        if (s->d_pack[k]) hipFree(s->d_pack[k]);
+        s->d_pack[k] = nullptr;
         if (s->d_fp[k]) hipFree(s->d_fp[k]);
         if (s->h_sym[k]) hipHostFree(s->h_sym[k]);
         if (s->h_fp[k]) hipHostFree(s->h_fp[k]);
@@ -283,6 +297,7 @@ int qpsk_multi_load(qpsk_multi *mj, long long total_frames, const float *h_in)
         bool ok = hipSetDevice(s->device) == hipSuccess && hipMalloc((void **)&s->d_in, n * frame_bytes) == hipSuccess;
         for (int k = 0; k < 2 && ok; k++)
             ok = hipMalloc((void **)&s->d_sym[k], n * (size_t)mj->nsym) == hipSuccess &&
+                 hipMalloc((void **)&s->d_pack[k], n * ((size_t)(mj->nsym + 3) / 4)) == hipSuccess &&
                  hipMalloc((void **)&s->d_fp[k], sizeof(float) * 2 * n) == hipSuccess &&
                  hipHostMalloc((void **)&s->h_sym[k], n * (size_t)mj->nsym, hipHostMallocDefault) == hipSuccess &&
                  hipHostMalloc((void **)&s->h_fp[k], sizeof(float) * 2 * n, hipHostMallocDefault) == hipSuccess &&
@@ -328,6 +343,15 @@ int qpsk_multi_set_direct_output(qpsk_multi *mj, int slot, uint8_t *h_sym, float
         s->dir_freq[slot] = h_freq;
         s->dir_phase[slot] = h_phase;
     }
+    return QPSK_OK;
+}
+
+int qpsk_multi_set_packed(qpsk_multi *mj, int on)
+{
+    if (!mj) return qpsk_set_error(QPSK_ERR_ARG, "qpsk_multi_set_packed: null job");
+    for (Shard *s : mj->shards)
+        if (s->in_flight[0] || s->in_flight[1]) return qpsk_set_error(QPSK_ERR_STATE, "qpsk_multi_set_packed: a slot is in flight");
+    mj->packed = on != 0;
     return QPSK_OK;
 }
 

@@ -54,6 +54,7 @@ API_SYMBOLS = [
     "qpsk_tx_reset", "qpsk_tx_symbols", "qpsk_test_inject_status", "qpsk_test_hist_state", "qpsk_ctx_check",
     "qpsk_multi_create", "qpsk_multi_destroy", "qpsk_multi_shards", "qpsk_multi_load", "qpsk_multi_shard", "qpsk_multi_use_device_input",
     "qpsk_multi_rx_begin", "qpsk_multi_rx_end", "qpsk_multi_set_direct_output", "qpsk_host_alloc", "qpsk_host_free",
+    "qpsk_multi_set_packed", "qpsk_pack_symbols", "qpsk_unpack_symbols_host",
 ]
 # every symbol include/qpsk_dropin.h declares
 DROPIN_SYMBOLS = [
@@ -131,6 +132,9 @@ def load():
     L.qpsk_multi_shard.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(vp), C.POINTER(vp)]
     L.qpsk_multi_use_device_input.argtypes = [vp, i32, vp]
     L.qpsk_multi_set_direct_output.argtypes = [vp, i32, vp, vp, vp]
+    L.qpsk_multi_set_packed.argtypes = [vp, i32]
+    L.qpsk_pack_symbols.argtypes = [vp, vp, C.c_longlong, i32, vp]
+    L.qpsk_unpack_symbols_host.argtypes = [vp, C.c_longlong, i32, vp]
     L.qpsk_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.qpsk_host_free.argtypes = [vp]
     L.qpsk_multi_rx_begin.argtypes = [vp, i32]
@@ -473,10 +477,20 @@ class MultiJob:
         p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)      # noqa: E731
         self._check(self.L.qpsk_multi_rx_end(self.h, slot, p(sym), p(freq), p(phase)))
 
+    def set_packed(self, on):
+        self._check(self.L.qpsk_multi_set_packed(self.h, int(bool(on))))
+        self.packed = bool(on)
+
+    def unpack(self, packed):
+        out = np.empty((packed.shape[0], self.nsym), np.uint8)
+        self._check(self.L.qpsk_unpack_symbols_host(packed.ctypes.data_as(C.c_void_p), packed.shape[0], self.nsym, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def pinned_outputs(self):
         """(sym, freq, phase) numpy views of page-locked memory (qpsk_host_alloc) for direct mode; kept alive by this object"""
         out = []
-        for shape, dt in (((self.total, self.nsym), np.uint8), ((self.total,), np.float32), ((self.total,), np.float32)):
+        cols = (self.nsym + 3) // 4 if getattr(self, "packed", False) else self.nsym
+        for shape, dt in (((self.total, cols), np.uint8), ((self.total,), np.float32), ((self.total,), np.float32)):
             nbytes = int(np.prod(shape)) * np.dtype(dt).itemsize
             p = C.c_void_p()
             self._check(self.L.qpsk_host_alloc(C.byref(p), nbytes))
@@ -490,7 +504,8 @@ class MultiJob:
         self._check(self.L.qpsk_multi_set_direct_output(self.h, slot, p(sym), p(freq), p(phase)))
 
     def outputs(self):
-        return (np.empty((self.total, self.nsym), np.uint8), np.empty(self.total, np.float32), np.empty(self.total, np.float32))
+        cols = (self.nsym + 3) // 4 if getattr(self, "packed", False) else self.nsym
+        return (np.empty((self.total, cols), np.uint8), np.empty(self.total, np.float32), np.empty(self.total, np.float32))
 
     def close(self):
         if getattr(self, "h", None):

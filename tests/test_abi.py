@@ -113,6 +113,20 @@ def test_multi_job_against_the_oracle(qpsk_lib, oracle):
     mj.end(1, *out1)
     for sym, freq, phase in (out0, out1):
         assert np.array_equal(sym, want["sym"]) and bits_equal(freq, want["freq"]) and bits_equal(phase, want["phase"])
+    # packed mode: four symbols per byte come back (16 MiB -> 4 MiB per 8192-frame step); unpacked on the host they are the oracle's
+    mj.set_packed(True)
+    pk = mj.outputs()
+    assert pk[0].shape == (F, (m.nsym + 3) // 4)
+    mj.begin(1)
+    mj.end(1, *pk)
+    assert np.array_equal(mj.unpack(pk[0]), want["sym"]) and bits_equal(pk[1], want["freq"])
+    ppin = mj.pinned_outputs()
+    mj.set_direct(0, *ppin)
+    mj.begin(0)
+    mj.end(0)
+    assert np.array_equal(ppin[0], pk[0]) and bits_equal(ppin[2], want["phase"])
+    mj.set_direct(0)
+    mj.set_packed(False)
     with pytest.raises(qpsk_amd.QpskError, match="nothing in flight"):
         mj.end(0)
     mj.begin(0)
@@ -121,6 +135,34 @@ def test_multi_job_against_the_oracle(qpsk_lib, oracle):
     mj.end(0, *out0)
     assert np.array_equal(out0[0], want["sym"])
     mj.close()
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,nsym", [(7, 2048), (33, 37), (5, 16), (3, 1), (1000, 130)])
+def test_pack_symbols(qpsk_lib, rows, nsym):
+    """qpsk_pack_symbols: four 2-bit symbols per byte, rows of ceil(nsym / 4) bytes (16 symbols per thread where nsym % 16 == 0, byte by byte
+    otherwise, the last byte of a row padded with zeros), and qpsk_unpack_symbols_host back"""
+    import numpy as np
+    import torch
+    import qpsk_amd
+    m = qpsk_amd.Modem(fs=19200.0, rs=2400.0, frame_size=1024)
+    rng = np.random.default_rng(rows * 1000 + nsym)
+    sym = rng.integers(0, 4, (rows, nsym), dtype=np.uint8)
+    d = torch.from_numpy(sym).cuda()
+    pb = (nsym + 3) // 4
+    out = torch.full((rows * pb + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    m._check(m.L.qpsk_pack_symbols(m.h, C.c_void_p(d.data_ptr()), rows, nsym, C.c_void_p(out.data_ptr())))
+    m.sync()
+    got = out.cpu().numpy()
+    assert np.all(got[rows * pb:] == 0xEE)
+    pad = np.zeros((rows, 4 * pb), np.uint8)
+    pad[:, :nsym] = sym
+    want = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    assert np.array_equal(got[:rows * pb].reshape(rows, pb), want)
+    back = np.empty((rows, nsym), np.uint8)
+    m._check(m.L.qpsk_unpack_symbols_host(want.ctypes.data_as(C.c_void_p), rows, nsym, back.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(back, sym)
     m.close()
 
 
