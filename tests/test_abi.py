@@ -190,6 +190,16 @@ def test_no_gpu_means_error_not_fallback(qpsk_lib):
     import qpsk_amd
     with pytest.raises(qpsk_amd.QpskError):
         qpsk_amd.Modem()
+    # the multi-device host layer (round 6) is no way round that: no device, no job
+    devs = (C.c_int32 * 2)(0, 0)
+    mj = C.c_void_p()
+    assert qpsk_lib.qpsk_multi_create(C.byref(mj), devs, 2, C.byref(p)) < 0 and not mj.value
+    assert qpsk_lib.qpsk_multi_create(C.byref(mj), devs, 0, C.byref(p)) == -2            # QPSK_ERR_ARG: no shard
+    assert qpsk_lib.qpsk_multi_rx_begin(None, 0) == -2 and qpsk_lib.qpsk_multi_shards(None) == 0
+    assert qpsk_lib.qpsk_unpack_symbols_host(None, 1, 4, None) == -2
+    pk = (C.c_uint8 * 2)(0b11100100, 0b00000010)                                        # symbols 0 1 2 3 | 2
+    out = (C.c_uint8 * 5)()
+    assert qpsk_lib.qpsk_unpack_symbols_host(pk, 1, 5, out) == 0 and list(out) == [0, 1, 2, 3, 2]      # plain host code: runs anywhere
 
 
 def test_bad_arguments_are_rejected(qpsk_lib):
