@@ -132,6 +132,12 @@ using GeomNarrow = Geom<16, 4, 4, 1, true>;
     (void)QL; (void)R; (void)FWV; (void)S; (void)CH; (void)WSLOTS; (void)DSTRIDE; (void)ZSTRIDE;         \
     (void)TSTEPS; (void)PAD; (void)MAX_NF
 
+#ifdef QPSK_PIPE_PROFILE
+/* measurement build, dbg bit 23: wall-clock stamps (100 MHz constant clock) of one rx_lean_kernel launch, 16 per workgroup: entry, the serial
+ * wave in costas_wave / at its first step / behind its last step / at its end, then the end of hardware wave w in slot 5 + w
+ * (tools/lean_timeline.py reads them through qpsk_prof_timeline) */
+__device__ unsigned long long g_timeline[1024 * 16];
+#endif
 struct Smem {
     float taps[128];
     int ready[MAX_WAVES];     /* chunks produced, per FIR wave */
@@ -276,7 +282,9 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
      * first chunk that starts from a loaded phase of -0, a last partial one and the variants below stay chunk by chunk */
 #ifdef QPSK_PIPE_PROFILE
     /* dbg bit 12 (4096): keep the ring stream under dbg 32 and time it (cycles inside the stream / waiting outside it) */
-    const bool ring_prof = (a.dbg & 4096) != 0 && (blockIdx.x == 0 || blockIdx.x == 77);
+    /* dbg bit 23 (8388608): every workgroup prints the wall-clock stamps of its waves (the launch's timeline across the chip) */
+    const bool timeline = (a.dbg & 8388608) != 0;
+    const bool ring_prof = (a.dbg & 4096) != 0 && (blockIdx.x == 0 || blockIdx.x == 77 || timeline);
     unsigned long long rp_in = 0, rp_out = 0, rp_t = 0, rp_calls = 0, rp_rt0 = 0, rp_rt1 = 0, rp_rt2 = 0;
     auto rp_real = [&]() {      /* the 100 MHz constant clock: wall time inside the launch */
         unsigned long long t = 0;
@@ -453,7 +461,12 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
 #ifdef QPSK_PIPE_PROFILE
     if (cprof && lane == 0 && !ring_prof)
         printf("serial wave: %d chunks; cycles per chunk: wait for the FIR waves %llu, steps %llu\n", nchunks, cw / nchunks, cs / nchunks);
-    if (ring_prof && lane == 0)
+    if (timeline) {
+        if (lane == 0 && blockIdx.x < 1024) {
+            unsigned long long *tl = g_timeline + 16 * blockIdx.x;
+            tl[1] = rp_rt0; tl[2] = rp_rt1; tl[3] = rp_rt2; tl[4] = rp_real();
+        }
+    } else if (ring_prof && lane == 0)
         printf("wg %3d serial wave: %d chunks, %llu entries into the stream; cycles per chunk inside the stream %llu (= %llu per step), "
                "outside it (waiting for the FIR waves, redone groups) %llu; wall time (100 MHz clock): wave start -> first step %.2f us, "
                "first -> last step %.2f us\n", (int)blockIdx.x, nchunks, rp_calls, rp_in / nchunks,
@@ -1687,6 +1700,14 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
     } else if (lane == 0) {
         __hip_atomic_store(&sm->abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+#ifdef QPSK_PIPE_PROFILE
+    if ((a.dbg & 8388608) && lane == 0) {
+        unsigned long long t;
+        __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (blockIdx.x < 1024 && hwave < 11) g_timeline[16 * blockIdx.x + 5 + hwave] = t;
+    }
+#endif
     if (!ok && lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
 }
 
@@ -1705,6 +1726,13 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
     const int f0 = blockIdx.x * G;
     const int nchunks = a.nsym / S;
 
+#ifdef QPSK_PIPE_PROFILE
+    if ((a.dbg & 8388608) && tid == 0) {
+        unsigned long long t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (blockIdx.x < 1024) g_timeline[16 * blockIdx.x] = t;
+    }
+#endif
     if (tid < MAX_WAVES) sm->ready[tid] = 0;
     if (tid == 0) { sm->consumed = 0; sm->abort_flag = 0; }
     /* ---- BASELINE config 3: the FFT timing estimate inside the launch (timing_fft_wave.h), as in rx_fused_pipe_kernel: every hardware
@@ -2283,3 +2311,12 @@ int prepare_pipe_kernel(void)
 }
 
 } // namespace qpsk
+
+#ifdef QPSK_PIPE_PROFILE
+/* measurement build only (libqpsk_hip_prof.so): the stamps of the last rx_lean_kernel launch under dbg bit 23 */
+extern "C" __attribute__((visibility("default"))) int qpsk_prof_timeline(unsigned long long *dst, int n)
+{
+    if (n > 1024 * 16) n = 1024 * 16;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(qpsk::g_timeline), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
