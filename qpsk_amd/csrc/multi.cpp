@@ -285,13 +285,16 @@ int qpsk_multi_load(qpsk_multi *mj, long long total_frames, const float *h_in)
     if (!mj || total_frames <= 0) return qpsk_set_error(QPSK_ERR_ARG, "qpsk_multi_load: null job or no frames");
     const long long N = (long long)mj->shards.size();
     const size_t frame_bytes = sizeof(float) * 2 * (size_t)mj->prm.frame_size;
-    mj->total = total_frames;
+    mj->total = 0;      /* no job until every shard stands: a failed load leaves nothing qpsk_multi_rx_begin would run on */
+    for (Shard *s : mj->shards) {
+        free_shard_buffers(s);
+        s->first = s->count = 0;
+    }
+    if ((total_frames + N - 1) / N > 0x7fffffffLL) return qpsk_set_error(QPSK_ERR_ARG, "qpsk_multi_load: more than 2^31 frames in a shard");
     for (long long r = 0; r < N; r++) {
         Shard *s = mj->shards[(size_t)r];
-        free_shard_buffers(s);
         s->first = r * total_frames / N;
         s->count = (r + 1) * total_frames / N - s->first;
-        if (s->count > 0x7fffffffLL) return qpsk_set_error(QPSK_ERR_ARG, "qpsk_multi_load: more than 2^31 frames in a shard");
         if (s->count == 0) continue;
         const size_t n = (size_t)s->count;
         bool ok = hipSetDevice(s->device) == hipSuccess && hipMalloc((void **)&s->d_in, n * frame_bytes) == hipSuccess;
@@ -304,8 +307,15 @@ int qpsk_multi_load(qpsk_multi *mj, long long total_frames, const float *h_in)
                  hipEventRecord(s->copied[k], s->copy) == hipSuccess;      /* "the slot is free" */
         if (ok && h_in)
             ok = hipMemcpy(s->d_in, h_in + (size_t)s->first * 2 * (size_t)mj->prm.frame_size, n * frame_bytes, hipMemcpyHostToDevice) == hipSuccess;
-        if (!ok) return qpsk_set_error(QPSK_ERR_ALLOC, "qpsk_multi_load: allocation or upload of a shard failed");
+        if (!ok) {
+            for (Shard *t : mj->shards) {
+                free_shard_buffers(t);
+                t->first = t->count = 0;
+            }
+            return qpsk_set_error(QPSK_ERR_ALLOC, "qpsk_multi_load: allocation or upload of a shard failed");
+        }
     }
+    mj->total = total_frames;
     return QPSK_OK;
 }
 
@@ -326,8 +336,9 @@ int qpsk_multi_use_device_input(qpsk_multi *mj, int r, const float *d_in)
     if (!mj || r < 0 || r >= (int)mj->shards.size() || !d_in) return qpsk_set_error(QPSK_ERR_ARG, "qpsk_multi_use_device_input: bad argument");
     Shard *s = mj->shards[(size_t)r];
     if (s->count == 0) return qpsk_set_error(QPSK_ERR_STATE, "qpsk_multi_use_device_input: call qpsk_multi_load first");
-    hipSetDevice(s->device);
-    hipStreamSynchronize(s->compute);
+    if (s->in_flight[0] || s->in_flight[1]) return qpsk_set_error(QPSK_ERR_STATE, "qpsk_multi_use_device_input: a slot is in flight");
+    if (hipSetDevice(s->device) != hipSuccess || hipStreamSynchronize(s->compute) != hipSuccess)
+        return qpsk_set_error(QPSK_ERR_HIP, "qpsk_multi_use_device_input: the shard's device or stream is not usable");
     if (s->d_in && !s->borrowed) hipFree(s->d_in);
     s->d_in = const_cast<float *>(d_in);
     s->borrowed = true;
