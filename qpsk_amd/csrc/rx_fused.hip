@@ -136,7 +136,8 @@ using GeomNarrow = Geom<16, 4, 4, 1, true>;
 /* measurement build, dbg bit 23: wall-clock stamps (100 MHz constant clock) of one rx_lean_kernel launch, 16 per workgroup: entry, the serial
  * wave in costas_wave / at its first step / behind its last step / at its end, then the end of hardware wave w in slot 5 + w
  * (tools/lean_timeline.py reads them through qpsk_prof_timeline) */
-__device__ unsigned long long g_timeline[1024 * 16];
+__device__ unsigned long long g_timeline[1024 * 48];
+#define QPSK_TL_STAMP(SLOT) do { if ((a.dbg & 8388608) && lane == 0 && blockIdx.x < 1024) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); g_timeline[48 * blockIdx.x + (SLOT)] = t_; } } while (0)
 #endif
 struct Smem {
     float taps[128];
@@ -463,7 +464,7 @@ __device__ __forceinline__ void costas_wave(const FusedArgs &a, SM *sm, const fl
         printf("serial wave: %d chunks; cycles per chunk: wait for the FIR waves %llu, steps %llu\n", nchunks, cw / nchunks, cs / nchunks);
     if (timeline) {
         if (lane == 0 && blockIdx.x < 1024) {
-            unsigned long long *tl = g_timeline + 16 * blockIdx.x;
+            unsigned long long *tl = g_timeline + 48 * blockIdx.x;
             tl[1] = rp_rt0; tl[2] = rp_rt1; tl[3] = rp_rt2; tl[4] = rp_real();
         }
     } else if (ring_prof && lane == 0)
@@ -1650,6 +1651,9 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
 #undef QPSK_LEAN_ABLATED
     } else
 #endif
+#ifdef QPSK_PIPE_PROFILE
+    QPSK_TL_STAMP(32 + hwave);     /* in front of the stream (parameters written, not yet the DMA table) */
+#endif
     if (use_dma) {
         /* Window staging by LDS-DMA (fir_lean_asm.h, the _dma loops): every decimation offset of the wave's frames is even, so the
          * 16-byte pairs of the window image are 16-byte pairs of the input.  The table the stream reads first, left in the still
@@ -1705,7 +1709,7 @@ __device__ __forceinline__ void fir_wave_lean(const FusedArgs &a, lean::Ctl *sm,
         unsigned long long t;
         __builtin_amdgcn_s_waitcnt(0);
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        if (blockIdx.x < 1024 && hwave < 11) g_timeline[16 * blockIdx.x + 5 + hwave] = t;
+        if (blockIdx.x < 1024 && hwave < 11) g_timeline[48 * blockIdx.x + 5 + hwave] = t;
     }
 #endif
     if (!ok && lane == 0) report_status(status, STATUS_PIPE_TIMEOUT);
@@ -1730,7 +1734,7 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
     if ((a.dbg & 8388608) && tid == 0) {
         unsigned long long t;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        if (blockIdx.x < 1024) g_timeline[16 * blockIdx.x] = t;
+        if (blockIdx.x < 1024) g_timeline[48 * blockIdx.x] = t;
     }
 #endif
     if (tid < MAX_WAVES) sm->ready[tid] = 0;
@@ -1792,6 +1796,9 @@ rx_lean_kernel(FusedArgs a, unsigned long long layout, int nwin, int *status)
     }
     const int mine = wave < 16 ? (int)((layout >> (4 * wave)) & 15) : 0;
     if (mine == 0) return;
+#ifdef QPSK_PIPE_PROFILE
+    QPSK_TL_STAMP(16 + wave);      /* a FIR wave behind the workgroup's barrier */
+#endif
     int u0 = 0, widx = 0;
     for (int v = 1; v < wave; v++) {
         const int cv = (int)((layout >> (4 * v)) & 15);
@@ -2316,7 +2323,7 @@ int prepare_pipe_kernel(void)
 /* measurement build only (libqpsk_hip_prof.so): the stamps of the last rx_lean_kernel launch under dbg bit 23 */
 extern "C" __attribute__((visibility("default"))) int qpsk_prof_timeline(unsigned long long *dst, int n)
 {
-    if (n > 1024 * 16) n = 1024 * 16;
+    if (n > 1024 * 48) n = 1024 * 48;
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(qpsk::g_timeline), sizeof(unsigned long long) * (size_t)n);
 }
 #endif

@@ -52,17 +52,18 @@ print("==== %d frames, %s, %s: %.4f ms per launch without stamps (20 back to bac
       % (frames, st, m.last_kernel(), base, e0.elapsed_time(e1)), flush=True)
 G = frames // 256 if frames % 256 == 0 else 16
 nwg = (frames + G - 1) // G
-buf = (ctypes.c_ulonglong * (16 * 1024))()
+buf = (ctypes.c_ulonglong * (48 * 1024))()
 lib = ctypes.CDLL(PROF)
 lib.qpsk_prof_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
-rc = lib.qpsk_prof_timeline(buf, 16 * 1024)
+rc = lib.qpsk_prof_timeline(buf, 48 * 1024)
 if rc:
     raise SystemExit("qpsk_prof_timeline: %d" % rc)
 wgs = []
 for b in range(1024):
-    r = buf[16 * b:16 * b + 16]
+    r = buf[48 * b:48 * b + 48]
     if r[0] and r[3]:
-        wgs.append({"entry": r[0], "start": r[1], "first": r[2], "last": r[3], "end": r[4], "fir": [v for v in r[5:] if v]})
+        wgs.append({"entry": r[0], "start": r[1], "first": r[2], "last": r[3], "end": r[4], "fir": [v for v in r[5:16] if v],
+                    "fir_barrier": [v for v in r[16:32] if v], "fir_stream": [v for v in r[32:48] if v]})
 t0 = min(w["entry"] for w in wgs)
 t1 = max(max([w["end"]] + w["fir"]) for w in wgs)
 us = lambda v: 0.01 * v
@@ -76,6 +77,8 @@ def stats(name, vals):
 print("%d workgroups stamped; first entry -> last wave's end: %.2f us" % (len(wgs), us(t1 - t0)))
 stats("entry after the first workgroup's", [w["entry"] - t0 for w in wgs])
 stats("entry -> the serial wave is in costas_wave", [w["start"] - w["entry"] for w in wgs])
+stats("entry -> the last FIR wave is behind the barrier", [max(w["fir_barrier"]) - w["entry"] for w in wgs if w["fir_barrier"]])
+stats("entry -> the last FIR wave enters its stream", [max(w["fir_stream"]) - w["entry"] for w in wgs if w["fir_stream"]])
 stats("... -> its first step (first chunk of every unit is there)", [w["first"] - w["start"] for w in wgs])
 stats("first -> last step", [w["last"] - w["first"] for w in wgs])
 stats("last step -> the serial wave's end", [w["end"] - w["last"] for w in wgs])
