@@ -132,9 +132,23 @@ def test_multi_job_against_the_oracle(qpsk_lib, oracle):
     mj.begin(0)
     with pytest.raises(qpsk_amd.QpskError, match="still in flight"):
         mj.begin(0)
+    import torch
+    lent = torch.from_numpy(x[a["count"]:].view(np.float32).reshape(b["count"], L, 2).copy()).cuda()
+    with pytest.raises(qpsk_amd.QpskError, match="in flight"):      # an input buffer is not swapped under a running step
+        mj.use_device_input(1, lent)
     mj.end(0, *out0)
     assert np.array_equal(out0[0], want["sym"])
+    # the caller's own device buffer as shard 1's input (no upload of that shard's frames by the job): same results
+    mj.use_device_input(1, lent)
+    mj.begin(1)
+    mj.end(1, *out1)
+    assert np.array_equal(out1[0], want["sym"]) and bits_equal(out1[1], want["freq"])
     mj.close()
+    # a job that was never loaded has nothing to run
+    mj2 = qpsk_amd.MultiJob([0], fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    with pytest.raises(qpsk_amd.QpskError, match="load a job first"):
+        mj2.begin(0)
+    mj2.close()
     m.close()
 
 
