@@ -624,7 +624,7 @@ def test_full_size_config2_histogram_timing(oracle):
     (a) a spread sample of frames against the oracle in TIMING_HIST mode, bit for bit, index included; (b) every
     frame's index equals what the three-kernel path (rrc_fir -> scan) finds; (c) the frames that got
     index i (an amplitude-bin number; nearly all frames share one) must give, bit for bit, what a batch of
-    them gives with that index fixed."""
+    them gives with that index fixed; (d) round 6: the one-pass route on the same batch equals the two-launch route in every output."""
     import torch
     import bench
     fs, rs, L, F = bench.FS, bench.RS, 16384, 4096
@@ -636,6 +636,16 @@ def test_full_size_config2_histogram_timing(oracle):
     want = oracle.rx_batch(x[torch.from_numpy(pick).cuda()].cpu().numpy(), fs, rs, loop_bw=BW, timing_mode=TIMING_HIST)
     for k in ("sym", "phase", "freq", "hz", "index"):
         assert bits_equal(cpu(a[k])[pick], want[k]), k
+    # round 6: the same batch again on the ONE-PASS route (rx_hist_kernel on the first call's majority index, the frames off it through
+    # the fall-back pass): every output of every frame as the two-launch route left it
+    assert "rx_hist_kernel" not in mh.last_kernel()
+    mh.tune(hist_onepass=1)
+    a1 = mh.rx_batch(x)
+    mh.sync()
+    assert "rx_hist_kernel" in mh.last_kernel(), mh.last_kernel()
+    for k in ("sym", "phase", "freq", "hz", "index"):
+        assert bits_equal(cpu(a1[k]), cpu(a[k])), k
+    mh.tune(hist_onepass=0)
     mh.tune(hist_generic=1)
     b = mh.rx_batch(x)
     mh.sync()
