@@ -467,6 +467,42 @@ def test_ragged_batches_ride_in_one_launch(oracle, F, mode):
     assert_batch_equal(got, want, keys=("sym", "phase", "freq", "index", "hz"))
 
 
+def test_full_size_ragged_batch_properties(oracle):
+    """config 2's frame size with a batch that is not whole workgroups (4097 and 8191 frames x 16384 samples, one launch of rx_lean_kernel
+    with pad frames): frames are independent (qpsk.c:36-53), so (a) every frame of the ragged batch equals the same frame of the whole
+    batch it extends / is cut from, bit for bit, (b) its last frames equal what a small batch of them gives, (c) a spread sample equals
+    the oracle, (d) nothing is written behind the outputs."""
+    import torch
+    import bench
+    fs, rs, L = bench.FS, bench.RS, 16384
+    m = modem(fs=fs, rs=rs, frame_size=L, timing_mode=TIMING_FIXED, fixed_index=6)
+    N = m.nsym
+    dev = torch.device("cuda", 0)
+    x = bench.synth_frames_gpu(torch, dev, 8192, m.taps, seed=21)
+
+    def run(first, count, lean=True):
+        sym = torch.full((count * N + 4096,), 0xEE, dtype=torch.uint8, device=dev)
+        fr = torch.full((count + 64,), 7.0, dtype=torch.float32, device=dev)
+        ph = torch.full((count + 64,), 7.0, dtype=torch.float32, device=dev)
+        m.rx_batch_raw(x[first:first + count], count, sym, fr, ph)
+        m.sync()
+        assert not lean or m.last_kernel() == "rx_lean_kernel", m.last_kernel()
+        assert bool((sym[count * N:] == 0xEE).all()) and bool((fr[count:] == 7.0).all()) and bool((ph[count:] == 7.0).all()), "wrote behind the batch"
+        return cpu(sym[:count * N]).reshape(count, N), cpu(fr[:count]), cpu(ph[:count])
+
+    whole = run(0, 8192)
+    for first, count in ((0, 4097), (1, 8191), (4095, 4097)):
+        got = run(first, count)
+        for g, w in zip(got, whole):
+            assert bits_equal(g, w[first:first + count]), (first, count)
+    tail = run(8192 - 5, 5, lean=False)      # (whatever kernel serves five frames)
+    for g, w in zip(tail, whole):
+        assert bits_equal(g, w[8192 - 5:])
+    pick = np.unique(np.concatenate([np.arange(0, 8192, 397), [4095, 4096, 8190, 8191]]))
+    want = oracle.rx_batch(x[torch.from_numpy(pick).to(dev)].cpu().numpy(), fs, rs, loop_bw=BW, timing_mode=TIMING_FIXED, fixed_index=6)
+    assert np.array_equal(whole[0][pick], want["sym"]) and bits_equal(whole[1][pick], want["freq"]) and bits_equal(whole[2][pick], want["phase"])
+
+
 def test_stream_calls_are_all_or_poisoned(oracle):
     """include/qpsk_hip.h, STREAMS, error contract (no test reached these paths): a kernel of a stream call reports that it
     gave up a bounded wait (injected through qpsk_test_inject_status: the status word a kernel would have written) -> the call that
