@@ -340,6 +340,7 @@ typedef struct qpsk_multi qpsk_multi;
 int qpsk_multi_create(qpsk_multi **out, const int *devices, int ndev, const qpsk_params *p);
 void qpsk_multi_destroy(qpsk_multi *mj);
 int qpsk_multi_shards(const qpsk_multi *mj);
+/* (a failed load -- QPSK_ERR_ALLOC -- frees what it had allocated and leaves the job without frames: rx_begin then returns QPSK_ERR_ARG) */
 int qpsk_multi_load(qpsk_multi *mj, long long total_frames, const float *h_in);
 /* shard r: its device, first frame and frame count, context and device input buffer (any pointer may be NULL) */
 int qpsk_multi_shard(qpsk_multi *mj, int r, int *device, long long *first, long long *count, qpsk_ctx **ctx, float **d_in);
